@@ -1,0 +1,147 @@
+"""ctypes bindings of the in-tree native libraries (include/focr_ncc.h, include/focr_host.h).
+
+Nothing here computes: it only declares the C ABI.  The HIP library is loaded
+lazily and loudly — there is no CPU fallback for the scan.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+
+class Match(C.Structure):
+    """focr_match_t == reference Match (src/ncc.cpp:7-10) / MatchC (src/ncc.rs:66-72)."""
+
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("similarity", C.c_float)]
+
+
+class Template(C.Structure):
+    """focr_template_t (include/focr_ncc.h)."""
+
+    _fields_ = [
+        ("letter", C.c_uint32),
+        ("n_w", C.c_uint16),
+        ("n_h", C.c_uint16),
+        ("offset", C.c_uint32),
+        ("shift_x", C.c_uint16),
+        ("shift_y", C.c_uint16),
+        ("off_x", C.c_float),
+        ("off_y", C.c_float),
+        ("corrected_off_y", C.c_float),
+        ("bearing_x", C.c_float),
+    ]
+
+
+class Hit(C.Structure):
+    """focr_hit_t (include/focr_ncc.h) == MatchWithLetter (src/ncc.rs:74-79)."""
+
+    _fields_ = [
+        ("x", C.c_uint16),
+        ("y", C.c_uint16),
+        ("w", C.c_uint16),
+        ("h", C.c_uint16),
+        ("similarity", C.c_float),
+        ("letter", C.c_uint32),
+        ("template_index", C.c_uint32),
+    ]
+
+
+class BankStruct(C.Structure):
+    """focr_bank_t (include/focr_host.h)."""
+
+    _fields_ = [
+        ("templates", C.POINTER(Template)),
+        ("n_templates", C.c_size_t),
+        ("needles", C.POINTER(C.c_uint8)),
+        ("needles_len", C.c_size_t),
+        ("n_alphabet", C.c_uint32),
+        ("x_bits", C.c_uint32),
+        ("y_bits", C.c_uint32),
+        ("text_size", C.c_float),
+        ("advance_px", C.c_float),
+    ]
+
+
+_NCC_ARGS = [
+    C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+    C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+]
+
+# every symbol include/focr_ncc.h declares: name -> (restype, argtypes)
+HIP_SYMBOLS = {
+    "ncc_8_u8": (C.c_size_t, _NCC_ARGS),
+    "ncc_16_u8": (C.c_size_t, _NCC_ARGS),
+    "focr_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "focr_ctx_destroy": (None, [C.c_void_p]),
+    "focr_last_error": (C.c_char_p, [C.c_void_p]),
+    "focr_last_error_global": (C.c_char_p, []),
+    "focr_device_count": (C.c_int, []),
+    "focr_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "focr_pages_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "focr_pages_upload": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "focr_pages_upload_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "focr_scan": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_int]),
+    "focr_get_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "focr_total_matches": (C.c_size_t, [C.c_void_p]),
+    "focr_get_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "focr_process_hits": (C.c_int, [C.c_void_p, C.c_float, C.c_int32]),
+    "focr_total_chars": (C.c_size_t, [C.c_void_p]),
+    "focr_total_lines": (C.c_size_t, [C.c_void_p]),
+    "focr_get_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "focr_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "focr_last_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "focr_sync": (C.c_int, [C.c_void_p]),
+    "focr_debug_rnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+HOST_SYMBOLS = {
+    "focr_bank_free": (None, [C.POINTER(BankStruct)]),
+    "focr_bank_save": (C.c_int, [C.c_char_p, C.POINTER(BankStruct)]),
+    "focr_bank_load": (C.c_int, [C.c_char_p, C.POINTER(BankStruct)]),
+    "focr_image_load_luma8": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "focr_image_save_pgm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "focr_synth_page": (C.c_size_t, [C.POINTER(BankStruct), C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_size_t]),
+    "focr_format_f32": (C.c_size_t, [C.c_float, C.c_char_p, C.c_size_t]),
+}
+
+RASTER_SYMBOLS = {
+    "focr_raster_bank": (C.c_int, [C.c_char_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.c_int, C.c_uint32, C.c_uint32, C.POINTER(BankStruct), C.c_char_p, C.c_size_t]),
+}
+
+_cache = {}
+
+
+def _load(name, symbols, mode=C.DEFAULT_MODE):
+    if name in _cache:
+        return _cache[name]
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the native libraries first "
+            f"(python -c 'import __graft_entry__ as g; g.build()' or make -C font_ocr_amd/csrc). "
+            f"There is no CPU fallback."
+        )
+    lib = C.CDLL(path, mode=mode)
+    for sym, (restype, argtypes) in symbols.items():
+        fn = getattr(lib, sym)  # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _cache[name] = lib
+    return lib
+
+
+def hip():
+    """libfocr_hip.so — the HIP product path.  Raises if it is not built."""
+    return _load("libfocr_hip.so", HIP_SYMBOLS)
+
+
+def host():
+    return _load("libfocr_host.so", HOST_SYMBOLS)
+
+
+def raster():
+    return _load("libfocr_raster.so", RASTER_SYMBOLS)

@@ -1,0 +1,192 @@
+/*
+ * focr_ncc.h — C ABI of the MI355X-native NCC template-matching scan.
+ *
+ * This is the drop-in boundary for the hot path of aconz2/font-ocr's `ncc`
+ * tool.  Everything is `extern "C"`, plain pointers and sizes; no C++ or
+ * torch types.  Implemented by font_ocr_amd/csrc (libfocr_hip.so), hand-written
+ * HIP for gfx950.  There is no CPU fallback: every compute entry point fails
+ * (FOCR_ERR_NO_DEVICE / returns 0 matches and sets the error string) when no
+ * HIP device is usable.
+ *
+ * Two layers:
+ *
+ *  (1) The reference's own FFI symbols, `ncc_8_u8` / `ncc_16_u8`
+ *      (reference: src/ncc.cpp:48-63 and 253-268; Rust declarations
+ *      src/ncc.rs:92-126).  Same names, same parameters, same return
+ *      convention, so the reference's Rust host links against this library
+ *      unchanged.  One call = one template over one page.
+ *
+ *  (2) A batched API (`focr_*`) that the reference's per-page driver
+ *      (get_hits / Searcher, src/ncc.rs:544-721, 231-404) maps onto: upload a
+ *      template bank once, keep N pages resident in HBM, scan all
+ *      (page x template) pairs in one pass, read back per-template match
+ *      lists that are identical to what N x T calls of (1) would return, and
+ *      optionally run the anchor/line/overlap post-process (process_hits,
+ *      src/ncc.rs:723-786) on the device.
+ */
+#ifndef FOCR_NCC_H
+#define FOCR_NCC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Wire format of one match: reference `Match` (src/ncc.cpp:7-10) == `MatchC`
+ * (src/ncc.rs:66-72).  8 bytes, repr(C). */
+typedef struct focr_match {
+    uint16_t x, y;
+    float similarity;
+} focr_match_t;
+
+/* MAX_MATCHES, src/ncc.rs:31: the reference gives every kernel call a
+ * 1024-entry output buffer; a scan stops once it is full. */
+#define FOCR_MAX_MATCHES 1024
+
+/* ------------------------------------------------------------------------ */
+/* (1) Drop-in kernels.  Replaces src/ncc.cpp:48-251 (ncc_8_u8) and
+ * src/ncc.cpp:253-396 (ncc_16_u8).
+ *
+ *  reference   r_w*r_h inverted grey page, row-major (caller-owned, host)
+ *  needle_u8   n_h rows of N bytes (N = 8 resp. 16), zero-padded past n_w
+ *  acc,acc_len caller scratch; the reference memsets it, so does this
+ *              implementation (contents after the call: all zero)
+ *  patch_sum   [r_h][r_w] window sums, valid on [start,end) of each row
+ *  patch_rnorm [r_h][r_w] 1/sqrt(window variance*n), same validity
+ *  start_end   [2*r_h] per-row [start,end) x-extent (src/ncc.rs:313-314)
+ *  threshold   emit iff sim > threshold and sim != +inf
+ *  out,n_out   caller buffer; returns the number of matches written, in
+ *              (y,x)-ascending order; == n_out means "full, scan stopped".
+ *
+ * Thread-safe: each calling thread gets its own device stream and staging
+ * buffers.  No error channel exists in the reference signature; on a device
+ * failure these return 0 and focr_last_error_global() describes it. */
+size_t ncc_8_u8(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w,
+                size_t n_h, uint32_t *acc, size_t acc_len, uint32_t *patch_sum,
+                double *patch_rnorm, uint16_t *start_end, float threshold, focr_match_t *out,
+                size_t n_out);
+size_t ncc_16_u8(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w,
+                 size_t n_h, uint32_t *acc, size_t acc_len, uint32_t *patch_sum,
+                 double *patch_rnorm, uint16_t *start_end, float threshold, focr_match_t *out,
+                 size_t n_out);
+
+/* ------------------------------------------------------------------------ */
+/* (2) Batched API. */
+
+typedef struct focr_ctx focr_ctx_t;
+
+enum {
+    FOCR_OK = 0,
+    FOCR_ERR_NO_DEVICE = 1,  /* no usable HIP device / runtime error (see focr_last_error) */
+    FOCR_ERR_INVALID = 2,    /* bad argument (sizes, null pointers, n_w > 16 ...) */
+    FOCR_ERR_STATE = 3,      /* call order (scan before bank/pages, results before scan) */
+    FOCR_ERR_OVERFLOW = 4,   /* internal candidate buffer could not be grown enough */
+    FOCR_ERR_NOMEM = 5
+};
+
+/* One template of the bank: a dense n_w x n_h A8 glyph raster (canvas pixels
+ * verbatim, src/ncc.rs:640-641, 894-896).  n_w <= 16 (the reference panics
+ * above that, src/ncc.rs:392), 1 <= n_h <= 32.  Templates are indexed in
+ * get_hits order: sub-pixel offset major, alphabet order minor
+ * (src/ncc.rs:587, 630). */
+typedef struct focr_template {
+    uint32_t letter;    /* Unicode code point (src/ncc.rs:676-680) */
+    uint16_t n_w, n_h;  /* canvas size */
+    uint32_t offset;    /* byte offset of the n_w*n_h pixels in `needles` */
+    uint16_t shift_x, shift_y; /* index of the sub-pixel offset on the x / y grid */
+    float off_x, off_y;        /* offset[0], offset[1] (src/ncc.rs:569) */
+    float corrected_off_y;     /* offset[1] + y_offset (src/ncc.rs:629) */
+    float bearing_x;           /* typographic left bearing in px (src/ncc.rs:673) */
+} focr_template_t;
+
+/* Which device formulation scans the bank.  Both give identical results. */
+enum {
+    FOCR_SCAN_MFMA = 0,   /* i8 MFMA conservative prefilter + exact verify (default, fast) */
+    FOCR_SCAN_DIRECT = 1  /* exact v_dot4 evaluation of every (window, template) */
+};
+
+/* One raw or post-processed hit with its template, as MatchWithLetter
+ * (src/ncc.rs:74-79): rect = (x, y, w, h). */
+typedef struct focr_hit {
+    uint16_t x, y;
+    uint16_t w, h;
+    float similarity;
+    uint32_t letter;
+    uint32_t template_index;
+} focr_hit_t;
+
+/* Context = one device + one stream + all buffers.  One per thread/GPU. */
+int focr_ctx_create(int device, focr_ctx_t **out);
+void focr_ctx_destroy(focr_ctx_t *ctx);
+const char *focr_last_error(const focr_ctx_t *ctx);
+const char *focr_last_error_global(void);
+int focr_device_count(void); /* 0 when no device / no driver */
+
+/* Upload the bank (replaces the per-page re-rasterisation + per-call needle
+ * padding of src/ncc.rs:587-649, 340-344, 367-371).  Copies everything. */
+int focr_bank_upload(focr_ctx_t *ctx, const focr_template_t *templates, size_t n_templates,
+                     const uint8_t *needles, size_t needles_len);
+
+/* Reserve n_pages resident pages of r_w x r_h (Searcher::new storage,
+ * src/ncc.rs:231-261, minus the tables this design does not need). */
+int focr_pages_alloc(focr_ctx_t *ctx, size_t n_pages, size_t r_w, size_t r_h);
+/* Copy `count` host pages (tightly packed r_w*r_h luma8 each) into slots
+ * [first, first+count).  invert != 0 applies image_to_u8's 255-px on the
+ * device (src/ncc.rs:887-892); invert == 0 means the bytes are already
+ * ink-high. */
+int focr_pages_upload(focr_ctx_t *ctx, size_t first, size_t count, const uint8_t *luma,
+                      int invert);
+/* Same, from a device pointer (pages already in HBM, e.g. a torch tensor). */
+int focr_pages_upload_device(focr_ctx_t *ctx, size_t first, size_t count, const void *d_luma,
+                             int invert);
+
+/* Scan every resident page with every template (Searcher::search_c_u8 for all
+ * templates of all pages, src/ncc.rs:332-404 + 587-701).  Asynchronous on the
+ * context's stream up to the point where result sizes are needed.
+ * threshold: as --threshold (src/ncc.rs:507).  cap: per-(page,template) match
+ * limit, FOCR_MAX_MATCHES for reference behaviour. */
+int focr_scan(focr_ctx_t *ctx, float threshold, uint32_t cap, int mode);
+
+/* Results of the last scan.  counts is [n_pages][n_templates] (value == cap
+ * means the reference would have warned "got >= 1024 matches",
+ * src/ncc.rs:395-397). */
+int focr_get_counts(focr_ctx_t *ctx, uint32_t *counts);
+size_t focr_total_matches(focr_ctx_t *ctx);
+/* All matches in (page, template, y, x) order; offsets is
+ * [n_pages*n_templates + 1] (CSR), matches has focr_total_matches entries. */
+int focr_get_matches(focr_ctx_t *ctx, uint64_t *offsets, focr_match_t *matches);
+
+/* process_hits on the device (src/ncc.rs:723-786 + partition_by 1036-1052)
+ * over the last scan's hits, for every page.  A page without hits yields zero
+ * lines (the reference panics there, src/ncc.rs:1040). */
+int focr_process_hits(focr_ctx_t *ctx, float anchor_threshold, int32_t overlap);
+size_t focr_total_chars(focr_ctx_t *ctx);
+size_t focr_total_lines(focr_ctx_t *ctx);
+/* page_line_offsets: [n_pages+1] index into line_char_offsets;
+ * line_char_offsets: [total_lines+1] index into chars; chars: [total_chars]. */
+int focr_get_lines(focr_ctx_t *ctx, uint64_t *page_line_offsets, uint64_t *line_char_offsets,
+                   focr_hit_t *chars);
+
+/* Device time (ms, HIP events on the context's stream) of the phases of the
+ * last focr_scan / focr_process_hits: [0] window statistics, [1] scan kernel
+ * (MFMA prefilter or direct), [2] exact verify, [3] ordering + cap,
+ * [4] process_hits, [5] whole scan.  For bench.py's roofline object. */
+int focr_last_timings(focr_ctx_t *ctx, float ms[6]);
+/* Work counters of the last scan: [0] candidates out of the prefilter,
+ * [1] hits before the cap, [2] algorithmic MACs (true template area x searched
+ * windows), [3] MACs issued incl. padding. */
+int focr_last_counters(focr_ctx_t *ctx, uint64_t c[4]);
+int focr_sync(focr_ctx_t *ctx);
+
+/* Device self-test hook used by the parity tests: evaluates
+ * 1/sqrt((double)s2 - (double)(s*s)/(double)n) on the device for n_items
+ * triples, so the f64 divide/sqrt rounding can be compared with the host's. */
+int focr_debug_rnorm(focr_ctx_t *ctx, const uint32_t *s, const uint64_t *s2, const uint32_t *n,
+                     size_t n_items, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCR_NCC_H */

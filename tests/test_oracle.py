@@ -1,0 +1,158 @@
+"""The oracle (CPU restatement, oracle/ncc_oracle.c) against the golden vectors produced by the
+reference's own compiled kernels (oracle/gen_golden.py), and — when oracle/_ref is present —
+against those kernels live.  No GPU."""
+import zlib
+
+import numpy as np
+import pytest
+
+from font_ocr_amd import synth_page
+from font_ocr_amd.bank import SYNTH_SEED_BASE
+from oracle import oracle as O
+
+
+def _run_case(c, use_ref=False):
+    page = c["page"]
+    r_h, r_w = page.shape
+    stats = (c["patch_sum"], c["patch_rnorm"], c["start_end"])
+    return O.ncc_u8(O.padded(page), r_w, r_h, c["needle"], stats, float(c["thr"]), int(c["cap"]), use_ref=use_ref)
+
+
+def test_kernel_cases_bit_exact(kernel_cases):
+    """oracle_ncc_u8 == reference ncc_8_u8/ncc_16_u8 on every committed vector (x, y and f32 bits)."""
+    assert len(kernel_cases) >= 20
+    for name, c in kernel_cases.items():
+        got = _run_case(c)
+        assert got.tobytes() == c["expect"].tobytes(), name
+
+
+def test_kernel_cases_order_and_cap(kernel_cases):
+    for name, c in kernel_cases.items():
+        e = c["expect"]
+        assert len(e) <= int(c["cap"])
+        key = e["y"].astype(np.int64) * 65536 + e["x"]
+        assert np.all(np.diff(key) > 0), name  # strictly (y,x)-ascending
+        if len(e):
+            assert e["x"].min() >= 1 and e["y"].min() >= 1, name  # x = 0 / y = 0 never searched
+    assert len(kernel_cases["cap_w8"]["expect"]) == 1024
+    assert len(kernel_cases["cap_small_17"]["expect"]) == 17
+    assert len(kernel_cases["blank"]["expect"]) == 0
+    assert len(kernel_cases["solid"]["expect"]) == 0  # sigma = 0 -> inf/NaN, never emitted
+    assert len(kernel_cases["space_needle"]["expect"]) == 0
+
+
+def test_prepare_for_size_matches_fixture_and_bruteforce(kernel_cases):
+    for name in ("text_w9", "noise_9x15", "edge_one_one", "solid_one_pixel"):
+        c = kernel_cases[name]
+        page = c["page"]
+        n_h, n_w = c["needle"].shape
+        ps, pr, se = O.prepare_for_size(page, n_w, n_h)
+        assert np.array_equal(se, c["start_end"]), name
+        r_h, r_w = page.shape
+        p64 = page.astype(np.int64)
+        for y in range(1, r_h - n_h + 1):
+            s, e = int(se[2 * y]), int(se[2 * y + 1])
+            if s < e:
+                assert np.array_equal(ps[y, s:e], c["patch_sum"][y, s:e])
+                assert np.array_equal(pr[y, s:e].view(np.uint64), c["patch_rnorm"][y, s:e].view(np.uint64))
+            for x in (s, (s + e) // 2, e - 1):
+                if s <= x < e:
+                    w = p64[y:y + n_h, x:x + n_w]
+                    assert int(ps[y, x]) == int(w.sum())
+                    norm = float((w * w).sum()) - float(int(w.sum()) ** 2) / float(n_w * n_h)
+                    expect = np.float64(1.0) / np.sqrt(np.float64(norm)) if norm != 0 else np.inf
+                    assert pr[y, x] == expect or (np.isnan(pr[y, x]) and np.isnan(expect))
+
+
+def test_sim_formula_against_float64_bruteforce(kernel_cases):
+    """Reported similarities agree with a direct float64 NCC (sanity of the whole formula)."""
+    c = kernel_cases["noise_9x15"]
+    page, nd = c["page"].astype(np.float64), c["needle"].astype(np.float64)
+    n_h, n_w = nd.shape
+    for m in c["expect"][:50]:
+        w = page[m["y"]:m["y"] + n_h, m["x"]:m["x"] + n_w]
+        a, b = w - w.mean(), nd - nd.mean()
+        ncc = (a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum())
+        assert abs(ncc - float(m["similarity"])) < 1e-6
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libncc_ref.so not present")
+def test_oracle_vs_live_reference_random():
+    """Seeded random pages/needles: restatement == compiled reference, bit for bit."""
+    rng = np.random.default_rng(7)
+    for it in range(40):
+        r_w, r_h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
+        n_w, n_h = int(rng.integers(1, 17)), int(rng.integers(1, 19))
+        if rng.random() < 0.5:
+            page = rng.integers(0, 256, (r_h, r_w), dtype=np.uint8)
+        else:  # sparse page: exercises start/end pruning
+            page = np.zeros((r_h, r_w), np.uint8)
+            k = int(rng.integers(0, 40))
+            page[rng.integers(0, r_h, k), rng.integers(0, r_w, k)] = rng.integers(1, 256, k)
+        y0, x0 = int(rng.integers(0, r_h - n_h + 1)), int(rng.integers(0, r_w - n_w + 1))
+        nd = page[y0:y0 + n_h, x0:x0 + n_w].copy() if rng.random() < 0.5 else rng.integers(0, 256, (n_h, n_w), dtype=np.uint8)
+        thr = float(rng.choice([-1.0, 0.0, 0.3, 0.8, 0.99]))
+        cap = int(rng.choice([1, 7, 1024]))
+        stats = O.prepare_for_size(page, n_w, n_h)
+        flat = O.padded(page)
+        a = O.ncc_u8(flat, r_w, r_h, nd, stats, thr, cap, use_ref=True)
+        b = O.ncc_u8(flat, r_w, r_h, nd, stats, thr, cap, use_ref=False)
+        assert a.tobytes() == b.tobytes(), (it, r_w, r_h, n_w, n_h, thr, cap)
+
+
+def test_c1_page_raw_hits(bank_default, c1_golden):
+    """configs[0]: one 608x720 page, 74-char alphabet, x-bits 0 — full scan == reference lists."""
+    page = c1_golden["page"]
+    again = synth_page(bank_default, SYNTH_SEED_BASE, 608, 720)
+    assert np.array_equal(page, again)  # the synthetic generator is deterministic
+    counts, matches = O.scan_page(O.invert(page), bank_default, 0.8)
+    assert np.array_equal(counts, c1_golden["counts"])
+    flat = np.concatenate([matches[t, : counts[t]] for t in range(len(counts))])
+    assert flat.tobytes() == c1_golden["matches"].tobytes()
+
+
+def test_c1_process_hits(bank_default, c1_golden):
+    counts = c1_golden["counts"]
+    cap = 1024
+    m = np.zeros((len(counts), cap), O.MATCH_DTYPE)
+    off = 0
+    for t, c in enumerate(counts):
+        m[t, :c] = c1_golden["matches"][off:off + c]
+        off += c
+    hits = O.raw_hits(counts, m, bank_default)
+    lines = O.process_hits(hits, 0.95, 5)
+    flat = np.concatenate(lines)
+    assert flat.tobytes() == c1_golden["lines"].tobytes()
+    assert np.array_equal(np.cumsum([len(l) for l in lines]), c1_golden["line_ends"])
+    # the text that was stamped is what comes back on the stamped lines
+    truth = c1_golden["truth"]
+    by_y = {int(l[0]["y"]): "".join(chr(c) for c in l["letter"]) for l in lines}
+    n_ok = 0
+    for y in sorted(set(truth["y"].tolist())):
+        want = "".join(chr(c) for c in truth[truth["y"] == y]["letter"])
+        n_ok += by_y.get(y) == want
+    assert n_ok >= 0.9 * len(set(truth["y"].tolist()))
+
+
+def test_process_hits_semantics():
+    """Anchored grouping + last-max tie-break (src/ncc.rs:755-764, 1042-1048)."""
+    def h(x, y, sim, letter):
+        return (x, y, 8, 15, sim, letter)
+
+    hits = np.array([
+        h(10, 5, 0.96, 65), h(14, 5, 0.90, 66), h(16, 5, 0.97, 67),  # 16-10 > 5: new group anchored at 16
+        h(21, 5, 0.97, 68),                                           # |21-16| <= 5 joins, ties -> last wins
+        h(50, 9, 0.90, 69),                                           # line y=9 has no anchor -> dropped
+        h(3, 2, 0.99, 70), h(3, 2, 0.99, 71),                         # same x, equal sim: last wins
+    ], dtype=O.HIT_DTYPE)
+    lines = O.process_hits(hits, 0.95, 5)
+    assert [int(l[0]["y"]) for l in lines] == [2, 5]
+    assert [int(c) for c in lines[0]["letter"]] == [71]
+    assert [int(c) for c in lines[1]["letter"]] == [65, 68]
+    assert O.process_hits(np.zeros(0, O.HIT_DTYPE)) == []
+
+
+def test_c2_golden_page_is_reproducible(bank_x2, c2_golden):
+    page = synth_page(bank_x2, SYNTH_SEED_BASE, 608, 720)
+    assert np.uint32(zlib.crc32(page.tobytes())) == c2_golden["page_crc"]
+    assert int(c2_golden["counts"].sum()) == len(c2_golden["matches"])
