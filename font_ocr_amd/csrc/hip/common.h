@@ -1,0 +1,152 @@
+// common.h — shared declarations of libfocr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "focr_ncc.h"
+
+namespace focr {
+
+// ---- geometry of one size class -------------------------------------------
+// A size class is the set of templates that share (n_w, n_h); window statistics
+// depend only on the class (reference: prepare_for_size is cached per size,
+// src/ncc.rs:264-268).
+struct SizeClass {
+    uint32_t n_w, n_h;
+    uint32_t ndw;          // dwords per padded template row in the direct kernel (1..4)
+    uint32_t maxh;         // padded row count in the direct kernel (16 or 32)
+    uint32_t n_templates;  // templates in this class
+    uint32_t first;        // index of the class's first entry in the class-ordered arrays
+    // MFMA prefilter layout
+    uint32_t rows_per_group;  // 2 if n_w <= 8 else 1: image rows packed in one 16-byte k-group
+    uint32_t k_groups;        // 16-byte k-groups per window (multiple of 4)
+    uint32_t n_tiles16;       // ceil(n_templates / 16)
+    uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
+    float kappa;              // prefilter slope: flag iff G > kappa * norm_p (see scan_mfma.hip)
+};
+
+// Per-template constants, computed once on the host in IEEE double exactly as
+// the reference's kernel prologue does (src/ncc.cpp:73-86, 278-291).
+struct TemplateConst {
+    double s_n;      // (double)s_n
+    double n_recip;  // 1 / n
+    double rnorm_n;  // 1 / sqrt(norm2_n)   (+inf for a constant needle)
+    uint32_t index;  // global template index (get_hits order)
+    uint32_t n_w, n_h;
+    uint32_t pad;
+};
+
+struct HitRecord {  // unordered device-side hit before ordering
+    uint64_t key;   // ((page * T + t) << 32) | (y << 16) | x
+};
+
+}  // namespace focr
+
+struct focr_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // bank
+    size_t n_templates = 0;
+    std::vector<focr_template_t> h_templates;
+    std::vector<focr::SizeClass> classes;
+    std::vector<focr::TemplateConst> h_tconst;  // class-ordered
+    focr::TemplateConst *d_tconst = nullptr;    // class-ordered
+    uint32_t *d_direct_bank = nullptr;          // class-ordered, [maxh][ndw] dwords each
+    std::vector<size_t> direct_bank_off;        // dword offset per class
+    int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter
+    uint8_t *d_needles = nullptr;               // dense needles (class-ordered, for verify)
+    std::vector<uint32_t> h_needle_off;         // class-ordered byte offsets into d_needles
+    uint32_t *d_needle_off = nullptr;
+    uint32_t *d_t_w = nullptr, *d_t_h = nullptr, *d_t_letter = nullptr;  // by global template index
+
+    // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded
+    size_t n_pages = 0, r_w = 0, r_h = 0, pitch = 0, rows_alloc = 0;
+    uint8_t *d_pages = nullptr;
+    uint8_t *d_stage = nullptr;  // device staging for uploads
+    size_t stage_bytes = 0;
+
+    // scan results
+    bool scanned = false;
+    uint32_t cap = FOCR_MAX_MATCHES;
+    size_t hit_capacity = 0;     // entries in d_hit_keys / d_hit_sims
+    uint64_t *d_hit_keys = nullptr, *d_hit_keys_alt = nullptr;
+    float *d_hit_sims = nullptr, *d_hit_sims_alt = nullptr;
+    uint32_t *d_counter = nullptr;  // [0] hits, [1] candidates, [2..] scratch
+    size_t cand_capacity = 0;
+    uint64_t *d_cand = nullptr;
+    int32_t *d_L = nullptr;  // prefilter thresholds [class][page][r_h][pitchL]
+    size_t L_bytes = 0;
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    size_t n_hits_raw = 0;    // hits before the cap
+    size_t n_cand = 0;
+    uint32_t *d_seg_count = nullptr;   // [n_pages*T] capped counts
+    uint64_t *d_seg_start = nullptr;   // [n_pages*T] start in the sorted arrays
+    uint64_t *d_seg_offset = nullptr;  // [n_pages*T + 1] CSR offsets of the capped lists
+    size_t seg_alloc = 0;
+    focr_match_t *d_matches = nullptr;  // capped, ordered
+    uint64_t *d_match_keys = nullptr;   // parallel to d_matches: (page<<48 | y<<32 | x<<16 | t)
+    size_t matches_alloc = 0;
+    size_t n_matches = 0;
+
+    // process_hits results
+    bool processed = false;
+    size_t n_chars = 0, n_lines = 0;
+    std::vector<uint64_t> h_page_line_off, h_line_char_off;
+    std::vector<focr_hit_t> h_chars;
+
+    hipEvent_t ev[8] = {};
+    float ms[6] = {};
+    uint64_t counters[4] = {};
+};
+
+namespace focr {
+
+void set_global_error(const std::string &s);
+int fail(focr_ctx *ctx, int code, const std::string &msg);
+
+#define FOCR_HIP(ctx, expr)                                                                       \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return focr::fail((ctx), FOCR_ERR_NO_DEVICE,                                          \
+                              std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+// launchers implemented in the .hip files
+int launch_scan_direct(focr_ctx *ctx, float threshold);
+int launch_scan_mfma(focr_ctx *ctx, float threshold);
+int order_hits(focr_ctx *ctx);
+int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
+
+// ---- device helpers: the reference's f64 epilogue, operation for operation ----
+// Compiled with -ffp-contract=off: the only fused operation is the explicit fma.
+
+// patch_rnorm, src/ncc.rs:309-311: 1 / sqrt(s2 - (s*s)/n), IEEE division and sqrt.
+__device__ __forceinline__ double window_rnorm(uint32_t s_p, uint64_t s2_p, double n_d) {
+    double norm = (double)s2_p - ((double)((uint64_t)s_p * (uint64_t)s_p)) / n_d;
+    return 1.0 / __builtin_sqrt(norm);
+}
+
+// similarity, src/ncc.cpp:352-361 (== 207-215): fnmadd(s_n * s_p, 1/n, acc) * (rnorm_n * rnorm_p)
+// with the vector path's signed int32 -> f64 conversions (_mm256_cvtepi32_pd).
+__device__ __forceinline__ double ncc_similarity(uint32_t acc, uint32_t s_p, double s_n_d, double n_recip,
+                                                 double rnorm_n, double rnorm_p) {
+    double num = __builtin_fma(-(s_n_d * (double)(int32_t)s_p), n_recip, (double)(int32_t)acc);
+    double den = rnorm_n * rnorm_p;
+    return num * den;
+}
+
+// emit test, src/ncc.cpp:362-366: (sim > thr) && !(sim == +inf); NaN fails both compares.
+__device__ __forceinline__ bool ncc_emits(double sim, double thr_d) {
+    return (sim > thr_d) && !(sim == __builtin_inf());
+}
+
+}  // namespace focr

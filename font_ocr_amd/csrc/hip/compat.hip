@@ -1,0 +1,213 @@
+// compat.hip — the reference's own FFI symbols on the GPU: ncc_8_u8 / ncc_16_u8
+// (replaces src/ncc.cpp:48-251 and 253-396; declared in src/ncc.rs:92-126).
+//
+// One call = one template over one page, with the caller's window tables
+// (patch_sum, patch_rnorm, start_end) honoured exactly as the reference kernel
+// reads them.  This entry point exists for drop-in linkage and parity testing;
+// throughput goes through the batched API (a single call moves 13 B/px of
+// tables over PCIe).
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace focr {
+
+int sort_pairs_u64_f32(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, float *&vals, float *&vals_alt, size_t n,
+                       unsigned end_bit);
+int ensure_hit_capacity(focr_ctx *c, size_t want);
+
+// one lane per window (x, y), x in [start_y, end_y), y in [1, y_searches)
+template <int N>
+__global__ __launch_bounds__(256) void compat_kernel(const uint8_t *__restrict__ ref, uint32_t r_w, uint32_t r_h,
+                                                     const uint8_t *__restrict__ needle, uint32_t n_w, uint32_t n_h,
+                                                     const uint32_t *__restrict__ patch_sum,
+                                                     const double *__restrict__ patch_rnorm,
+                                                     const uint16_t *__restrict__ start_end, double s_n, double n_recip,
+                                                     double rnorm_n, double thr_d, uint64_t *__restrict__ hit_keys,
+                                                     float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
+                                                     unsigned long long capacity) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t y = 1 + blockIdx.y;  // src/ncc.cpp:98, 302
+    const uint32_t start = start_end[2 * y], end = start_end[2 * y + 1];
+    if (x < start || x >= end || x + n_w > r_w) return;  // the last clause only guards insane caller tables
+    uint32_t acc = 0;
+    for (uint32_t j = 0; j < n_h; j++) {
+        const uint8_t *r = ref + (size_t)(y + j) * r_w + x;
+        const uint8_t *t = needle + j * N;
+        for (uint32_t i = 0; i < n_w; i++) acc += (uint32_t)t[i] * (uint32_t)r[i];  // padded columns are zero
+    }
+    const size_t o = (size_t)y * r_w + x;
+    const double sim = ncc_similarity(acc, patch_sum[o], s_n, n_recip, rnorm_n, patch_rnorm[o]);
+    if (ncc_emits(sim, thr_d)) {
+        unsigned long long idx = atomicAdd(counter, 1ull);
+        if (idx < capacity) {
+            hit_keys[idx] = ((uint64_t)y << 16) | (uint64_t)x;
+            hit_sims[idx] = (float)sim;
+        }
+    }
+}
+
+__global__ void compat_pack(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n,
+                            focr_match_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    focr_match_t m;
+    m.x = (uint16_t)(keys[i] & 0xffff);
+    m.y = (uint16_t)((keys[i] >> 16) & 0xffff);
+    m.similarity = sims[i];
+    out[i] = m;
+}
+
+struct CompatState {
+    focr_ctx *ctx = nullptr;
+    uint8_t *d_ref = nullptr, *d_needle = nullptr;
+    uint32_t *d_ps = nullptr;
+    double *d_pr = nullptr;
+    uint16_t *d_se = nullptr;
+    focr_match_t *d_out = nullptr;
+    size_t px_alloc = 0, rows_alloc = 0, out_alloc = 0;
+    // deliberately no destructor: thread-exit / process-exit order against the HIP runtime's own
+    // teardown is unspecified, and the driver reclaims everything anyway.
+};
+
+static thread_local CompatState tl;
+
+template <int N>
+static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w, size_t n_h,
+                          uint32_t *acc, size_t acc_len, uint32_t *patch_sum, double *patch_rnorm, uint16_t *start_end,
+                          float threshold, focr_match_t *out, size_t n_out) {
+    if (acc && acc_len) memset(acc, 0, sizeof(uint32_t) * acc_len);  // src/ncc.cpp:67, 272
+    if (!reference || !needle_u8 || !patch_sum || !patch_rnorm || !start_end || !out || n_out == 0) {
+        set_global_error("ncc_N_u8: null argument or n_out == 0");
+        return 0;
+    }
+    if (n_w == 0 || n_w > (size_t)N || n_h == 0 || n_h > r_h || n_w > r_w || r_w > 65535 || r_h > 65535) {
+        set_global_error("ncc_N_u8: unsupported geometry");
+        return 0;
+    }
+    const size_t y_searches = r_h - n_h + 1;
+    if (y_searches <= 1) return 0;
+    if (!tl.ctx) {
+        int dev = 0;
+        if (const char *e = getenv("FOCR_DEVICE")) dev = atoi(e);
+        if (focr_ctx_create(dev, &tl.ctx) != FOCR_OK) {
+            tl.ctx = nullptr;
+            return 0;  // focr_last_error_global() has the reason; no CPU fallback
+        }
+    }
+    focr_ctx *c = tl.ctx;
+    auto bail = [&](const char *what, hipError_t e) -> size_t {
+        fail(c, FOCR_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+        return 0;
+    };
+#define CK(expr)                                   \
+    do {                                           \
+        hipError_t e_ = (expr);                    \
+        if (e_ != hipSuccess) return bail(#expr, e_); \
+    } while (0)
+    CK(hipSetDevice(c->device));
+    const size_t npx = r_w * r_h;
+    if (tl.px_alloc < npx) {
+        CK(hipStreamSynchronize(c->stream));
+        for (void *p : {(void *)tl.d_ref, (void *)tl.d_ps, (void *)tl.d_pr})
+            if (p) (void)hipFree(p);
+        tl.d_ref = nullptr;
+        tl.d_ps = nullptr;
+        tl.d_pr = nullptr;
+        tl.px_alloc = 0;
+        CK(hipMalloc(&tl.d_ref, npx + 64));
+        CK(hipMalloc(&tl.d_ps, npx * 4));
+        CK(hipMalloc(&tl.d_pr, npx * 8));
+        tl.px_alloc = npx;
+    }
+    if (tl.rows_alloc < r_h) {
+        CK(hipStreamSynchronize(c->stream));
+        if (tl.d_se) (void)hipFree(tl.d_se);
+        tl.d_se = nullptr;
+        CK(hipMalloc(&tl.d_se, r_h * 2 * sizeof(uint16_t)));
+        tl.rows_alloc = r_h;
+    }
+    if (!tl.d_needle) CK(hipMalloc(&tl.d_needle, 16 * 65536));
+    if (n_h * N > 16 * 65536) {
+        set_global_error("ncc_N_u8: needle too tall");
+        return 0;
+    }
+
+    // kernel prologue, src/ncc.cpp:73-86 / 278-291, in host IEEE double
+    uint32_t s_n = 0, s2_n = 0;
+    for (size_t i = 0; i < n_h; i++)
+        for (size_t j = 0; j < (size_t)N; j++) {
+            s_n += needle_u8[i * N + j];
+            s2_n += (uint32_t)needle_u8[i * N + j] * (uint32_t)needle_u8[i * N + j];
+        }
+    const size_t n = n_w * n_h;
+    const double norm2_n = (double)s2_n - (double)((uint64_t)s_n * (uint64_t)s_n) / (double)n;
+    const double rnorm_n = 1. / std::sqrt(norm2_n);
+    const double n_recip = 1. / (double)n;
+
+    CK(hipMemcpyAsync(tl.d_ref, reference, npx, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(tl.d_ps, patch_sum, npx * 4, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(tl.d_pr, patch_rnorm, npx * 8, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(tl.d_se, start_end, r_h * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(tl.d_needle, needle_u8, n_h * N, hipMemcpyHostToDevice, c->stream));
+
+    size_t want = std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 16, n_out * 4));
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (ensure_hit_capacity(c, want) != FOCR_OK) return 0;
+        CK(hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        dim3 grid((unsigned)((r_w + 255) / 256), (unsigned)(y_searches - 1));
+        hipLaunchKernelGGL((compat_kernel<N>), grid, dim3(256), 0, c->stream, tl.d_ref, (uint32_t)r_w, (uint32_t)r_h,
+                           tl.d_needle, (uint32_t)n_w, (uint32_t)n_h, tl.d_ps, tl.d_pr, tl.d_se, (double)s_n, n_recip,
+                           rnorm_n, (double)threshold, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
+                           (unsigned long long)c->hit_capacity);
+        CK(hipGetLastError());
+        unsigned long long cnt = 0;
+        CK(hipMemcpyAsync(&cnt, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        CK(hipStreamSynchronize(c->stream));
+        if (cnt > c->hit_capacity) {
+            want = (size_t)cnt + 1024;
+            continue;
+        }
+        if (cnt == 0) return 0;
+        if (sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims, c->d_hit_sims_alt, (size_t)cnt, 32) != FOCR_OK)
+            return 0;
+        const size_t keep = std::min<size_t>((size_t)cnt, n_out);  // src/ncc.cpp:225-227, 371-373
+        if (tl.out_alloc < keep) {
+            CK(hipStreamSynchronize(c->stream));
+            if (tl.d_out) (void)hipFree(tl.d_out);
+            tl.d_out = nullptr;
+            CK(hipMalloc(&tl.d_out, keep * sizeof(focr_match_t)));
+            tl.out_alloc = keep;
+        }
+        hipLaunchKernelGGL(compat_pack, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, c->stream, c->d_hit_keys,
+                           c->d_hit_sims, keep, tl.d_out);
+        CK(hipGetLastError());
+        CK(hipMemcpyAsync(out, tl.d_out, keep * sizeof(focr_match_t), hipMemcpyDeviceToHost, c->stream));
+        CK(hipStreamSynchronize(c->stream));
+        return keep;
+    }
+#undef CK
+    set_global_error("ncc_N_u8: hit buffer kept overflowing");
+    return 0;
+}
+
+}  // namespace focr
+
+extern "C" {
+
+size_t ncc_8_u8(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w, size_t n_h, uint32_t *acc,
+                size_t acc_len, uint32_t *patch_sum, double *patch_rnorm, uint16_t *start_end, float threshold,
+                focr_match_t *out, size_t n_out) {
+    return focr::compat_call<8>(reference, r_w, r_h, needle_u8, n_w, n_h, acc, acc_len, patch_sum, patch_rnorm, start_end,
+                                threshold, out, n_out);
+}
+
+size_t ncc_16_u8(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w, size_t n_h, uint32_t *acc,
+                 size_t acc_len, uint32_t *patch_sum, double *patch_rnorm, uint16_t *start_end, float threshold,
+                 focr_match_t *out, size_t n_out) {
+    return focr::compat_call<16>(reference, r_w, r_h, needle_u8, n_w, n_h, acc, acc_len, patch_sum, patch_rnorm, start_end,
+                                 threshold, out, n_out);
+}
+
+}  // extern "C"

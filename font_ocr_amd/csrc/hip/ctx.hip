@@ -1,0 +1,403 @@
+// ctx.hip — context, bank upload, resident pages, result read-back (include/focr_ncc.h layer 2).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace focr {
+
+static std::mutex g_err_mu;
+static std::string g_err;
+
+void set_global_error(const std::string &s) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = s;
+}
+
+int fail(focr_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    set_global_error(msg);
+    return code;
+}
+
+// tight luma8 pages -> pitched ink-high pages (image_to_u8, src/ncc.rs:887-892, on the device)
+__global__ void ingest_pages(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t r_w, size_t r_h,
+                             size_t pitch, size_t rows_alloc, size_t first, size_t count, int invert) {
+    size_t total = count * r_h * r_w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t p = i / (r_h * r_w), rem = i % (r_h * r_w);
+        size_t y = rem / r_w, x = rem % r_w;
+        uint8_t v = src[i];
+        dst[((first + p) * rows_alloc + y) * pitch + x] = invert ? (uint8_t)(255 - v) : v;
+    }
+}
+
+__global__ void debug_rnorm_kernel(const uint32_t *s, const uint64_t *s2, const uint32_t *n, size_t cnt, double *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = window_rnorm(s[i], s2[i], (double)n[i]);
+}
+
+template <typename T>
+static void free_dev(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_bank(focr_ctx *c) {
+    free_dev(c->d_tconst);
+    free_dev(c->d_direct_bank);
+    free_dev(c->d_qbank);
+    free_dev(c->d_needles);
+    free_dev(c->d_needle_off);
+    free_dev(c->d_t_w);
+    free_dev(c->d_t_h);
+    free_dev(c->d_t_letter);
+    c->classes.clear();
+    c->h_tconst.clear();
+    c->h_templates.clear();
+    c->direct_bank_off.clear();
+    c->h_needle_off.clear();
+    c->n_templates = 0;
+}
+
+static void free_results(focr_ctx *c) {
+    free_dev(c->d_hit_keys);
+    free_dev(c->d_hit_keys_alt);
+    free_dev(c->d_hit_sims);
+    free_dev(c->d_hit_sims_alt);
+    free_dev(c->d_cand);
+    free_dev(c->d_L);
+    free_dev(c->d_sort_tmp);
+    free_dev(c->d_seg_count);
+    free_dev(c->d_seg_start);
+    free_dev(c->d_seg_offset);
+    free_dev(c->d_matches);
+    free_dev(c->d_match_keys);
+    c->hit_capacity = c->cand_capacity = c->L_bytes = c->sort_tmp_bytes = c->seg_alloc = c->matches_alloc = 0;
+    c->scanned = c->processed = false;
+}
+
+}  // namespace focr
+
+using namespace focr;
+
+extern "C" {
+
+const char *focr_last_error_global(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_err;
+    return copy.c_str();
+}
+
+const char *focr_last_error(const focr_ctx_t *ctx) { return ctx ? ctx->err.c_str() : focr_last_error_global(); }
+
+int focr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int focr_ctx_create(int device, focr_ctx_t **out) {
+    if (!out) return fail(nullptr, FOCR_ERR_INVALID, "focr_ctx_create: null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, FOCR_ERR_NO_DEVICE,
+                    std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                        "); this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(nullptr, FOCR_ERR_INVALID, "focr_ctx_create: bad device index");
+    focr_ctx *c = new focr_ctx();
+    c->device = device;
+    FOCR_HIP(c, hipSetDevice(device));
+    FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
+    FOCR_HIP(c, hipMalloc(&c->d_counter, 64 * sizeof(uint32_t)));
+    FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+    *out = c;
+    return FOCR_OK;
+}
+
+void focr_ctx_destroy(focr_ctx_t *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_bank(c);
+    free_results(c);
+    free_dev(c->d_pages);
+    free_dev(c->d_stage);
+    free_dev(c->d_counter);
+    for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int focr_sync(focr_ctx_t *c) {
+    if (!c) return FOCR_ERR_INVALID;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    return FOCR_OK;
+}
+
+int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
+                     size_t needles_len) {
+    if (!c || !templates || !n_templates || !needles) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: bad arguments");
+    if (n_templates > 65535) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: more than 65535 templates");
+    for (size_t t = 0; t < n_templates; t++) {
+        const focr_template_t &d = templates[t];
+        if (d.n_w == 0 || d.n_h == 0) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: empty template");
+        if (d.n_w > 16)  // the reference panics: "not handled", src/ncc.rs:392
+            return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template wider than 16 px is not handled (src/ncc.rs:392)");
+        if (d.n_h > 32) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template taller than 32 px is not handled");
+        if ((size_t)d.offset + (size_t)d.n_w * d.n_h > needles_len)
+            return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template offset out of range");
+    }
+    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    free_bank(c);
+    c->scanned = c->processed = false;
+    c->n_templates = n_templates;
+    c->h_templates.assign(templates, templates + n_templates);
+
+    // size classes in order of first appearance
+    std::vector<std::vector<uint32_t>> members;
+    for (size_t t = 0; t < n_templates; t++) {
+        size_t k = 0;
+        for (; k < c->classes.size(); k++)
+            if (c->classes[k].n_w == templates[t].n_w && c->classes[k].n_h == templates[t].n_h) break;
+        if (k == c->classes.size()) {
+            SizeClass sc{};
+            sc.n_w = templates[t].n_w;
+            sc.n_h = templates[t].n_h;
+            sc.ndw = (sc.n_w + 3) / 4;
+            sc.maxh = sc.n_h <= 16 ? 16 : 32;
+            c->classes.push_back(sc);
+            members.emplace_back();
+        }
+        members[k].push_back((uint32_t)t);
+    }
+
+    std::vector<uint32_t> direct;
+    std::vector<uint8_t> dense;
+    uint32_t first = 0;
+    for (size_t k = 0; k < c->classes.size(); k++) {
+        SizeClass &sc = c->classes[k];
+        sc.first = first;
+        sc.n_templates = (uint32_t)members[k].size();
+        first += sc.n_templates;
+        c->direct_bank_off.push_back(direct.size());
+        const uint32_t n = sc.n_w * sc.n_h;
+        for (uint32_t t : members[k]) {
+            const uint8_t *nd = needles + templates[t].offset;
+            // reference kernel prologue, src/ncc.cpp:73-86 / 278-291 (host IEEE double)
+            uint32_t s_n = 0, s2_n = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                s_n += nd[i];
+                s2_n += (uint32_t)nd[i] * nd[i];
+            }
+            double norm2_n = (double)s2_n - (double)((uint64_t)s_n * (uint64_t)s_n) / (double)n;
+            TemplateConst tc{};
+            tc.s_n = (double)s_n;
+            tc.n_recip = 1. / (double)n;
+            tc.rnorm_n = 1. / std::sqrt(norm2_n);
+            tc.index = t;
+            tc.n_w = sc.n_w;
+            tc.n_h = sc.n_h;
+            c->h_tconst.push_back(tc);
+            // direct-kernel layout: maxh rows of ndw dwords, zero padded
+            for (uint32_t j = 0; j < sc.maxh; j++)
+                for (uint32_t k4 = 0; k4 < sc.ndw; k4++) {
+                    uint32_t w = 0;
+                    for (uint32_t b = 0; b < 4; b++) {
+                        uint32_t i = k4 * 4 + b;
+                        if (j < sc.n_h && i < sc.n_w) w |= (uint32_t)nd[j * sc.n_w + i] << (8 * b);
+                    }
+                    direct.push_back(w);
+                }
+            c->h_needle_off.push_back((uint32_t)dense.size());
+            dense.insert(dense.end(), nd, nd + n);
+        }
+    }
+    std::vector<uint32_t> tw(n_templates), th(n_templates), tl(n_templates);
+    for (size_t t = 0; t < n_templates; t++) {
+        tw[t] = templates[t].n_w;
+        th[t] = templates[t].n_h;
+        tl[t] = templates[t].letter;
+    }
+    auto up = [&](auto *&dptr, const void *src, size_t bytes) -> int {
+        FOCR_HIP(c, hipMalloc((void **)&dptr, bytes ? bytes : 16));
+        FOCR_HIP(c, hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+        return FOCR_OK;
+    };
+    int rc;
+    if ((rc = up(c->d_tconst, c->h_tconst.data(), c->h_tconst.size() * sizeof(TemplateConst)))) return rc;
+    if ((rc = up(c->d_direct_bank, direct.data(), direct.size() * 4))) return rc;
+    if ((rc = up(c->d_needles, dense.data(), dense.size()))) return rc;
+    if ((rc = up(c->d_needle_off, c->h_needle_off.data(), c->h_needle_off.size() * 4))) return rc;
+    if ((rc = up(c->d_t_w, tw.data(), tw.size() * 4))) return rc;
+    if ((rc = up(c->d_t_h, th.data(), th.size() * 4))) return rc;
+    if ((rc = up(c->d_t_letter, tl.data(), tl.size() * 4))) return rc;
+    return build_mfma_bank(c, dense.data());
+}
+
+int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
+    if (!c || !n_pages || !r_w || !r_h) return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: bad arguments");
+    if (r_w > 65535 || r_h > 65535)  // Match.x/y and start_end are u16, src/ncc.cpp:7-10, src/ncc.rs:313-314
+        return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: page side above 65535 px");
+    if (n_pages > 65535) return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: more than 65535 pages per batch");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_pages);
+    c->scanned = c->processed = false;
+    c->n_pages = n_pages;
+    c->r_w = r_w;
+    c->r_h = r_h;
+    c->pitch = (r_w + 64 + 63) / 64 * 64;  // >= 64 zero bytes right of every row
+    c->rows_alloc = r_h + 48;              // >= 48 zero rows below every page
+    size_t bytes = c->n_pages * c->rows_alloc * c->pitch;
+    if (hipMalloc(&c->d_pages, bytes) != hipSuccess) {
+        c->d_pages = nullptr;
+        c->n_pages = 0;
+        return fail(c, FOCR_ERR_NOMEM, "focr_pages_alloc: hipMalloc failed");
+    }
+    FOCR_HIP(c, hipMemsetAsync(c->d_pages, 0, bytes, c->stream));
+    return FOCR_OK;
+}
+
+static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count, int invert) {
+    size_t total = count * c->r_h * c->r_w;
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(256), 0, c->stream, d_src, c->d_pages, c->r_w, c->r_h, c->pitch,
+                       c->rows_alloc, first, count, invert);
+    FOCR_HIP(c, hipGetLastError());
+    c->scanned = c->processed = false;
+    return FOCR_OK;
+}
+
+int focr_pages_upload(focr_ctx_t *c, size_t first, size_t count, const uint8_t *luma, int invert) {
+    if (!c || !luma) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload: bad arguments");
+    if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_pages_upload: call focr_pages_alloc first");
+    if (first + count > c->n_pages) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload: page range out of bounds");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    const size_t page_bytes = c->r_w * c->r_h;
+    const size_t chunk_pages = std::max<size_t>(1, (256u << 20) / page_bytes);
+    size_t need = std::min(count, chunk_pages) * page_bytes;
+    if (c->stage_bytes < need) {
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        free_dev(c->d_stage);
+        FOCR_HIP(c, hipMalloc(&c->d_stage, need));
+        c->stage_bytes = need;
+    }
+    for (size_t done = 0; done < count; done += chunk_pages) {
+        size_t n = std::min(chunk_pages, count - done);
+        FOCR_HIP(c, hipMemcpyAsync(c->d_stage, luma + done * page_bytes, n * page_bytes, hipMemcpyHostToDevice, c->stream));
+        int rc = ingest(c, c->d_stage, first + done, n, invert);
+        if (rc) return rc;
+        if (done + chunk_pages < count) FOCR_HIP(c, hipStreamSynchronize(c->stream));  // staging buffer reuse
+    }
+    return FOCR_OK;
+}
+
+int focr_pages_upload_device(focr_ctx_t *c, size_t first, size_t count, const void *d_luma, int invert) {
+    if (!c || !d_luma) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload_device: bad arguments");
+    if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_pages_upload_device: call focr_pages_alloc first");
+    if (first + count > c->n_pages) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload_device: page range out of bounds");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    return ingest(c, (const uint8_t *)d_luma, first, count, invert);
+}
+
+int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
+    if (!c) return FOCR_ERR_INVALID;
+    if (!c->n_templates) return fail(c, FOCR_ERR_STATE, "focr_scan: no bank uploaded");
+    if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_scan: no pages resident");
+    if (cap == 0) return fail(c, FOCR_ERR_INVALID, "focr_scan: cap must be >= 1 (src/ncc.cpp:43-46)");
+    if (mode != FOCR_SCAN_MFMA && mode != FOCR_SCAN_DIRECT) return fail(c, FOCR_ERR_INVALID, "focr_scan: bad mode");
+    if (std::isnan(threshold)) return fail(c, FOCR_ERR_INVALID, "focr_scan: threshold is NaN");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    c->cap = cap;
+    c->scanned = c->processed = false;
+    for (auto &m : c->ms) m = 0.f;
+    // algorithmic MACs, SURVEY.md section 8(d): true template area x searched windows
+    uint64_t macs = 0;
+    for (const SizeClass &sc : c->classes) {
+        if (sc.n_w > c->r_w || sc.n_h > c->r_h) continue;
+        uint64_t wx = c->r_w - sc.n_w, wy = c->r_h - sc.n_h;  // x in [1, r_w-n_w], y in [1, r_h-n_h]
+        macs += wx * wy * (uint64_t)sc.n_w * sc.n_h * sc.n_templates;
+    }
+    c->counters[2] = macs * c->n_pages;
+    c->counters[3] = 0;
+    int rc = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
+    if (rc) return rc;
+    rc = order_hits(c);
+    if (rc) return rc;
+    c->scanned = true;
+    return FOCR_OK;
+}
+
+int focr_get_counts(focr_ctx_t *c, uint32_t *counts) {
+    if (!c || !counts) return fail(c, FOCR_ERR_INVALID, "focr_get_counts: bad arguments");
+    if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_get_counts: no scan results");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP(c, hipMemcpyAsync(counts, c->d_seg_count, c->n_pages * c->n_templates * 4, hipMemcpyDeviceToHost, c->stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    return FOCR_OK;
+}
+
+size_t focr_total_matches(focr_ctx_t *c) { return (c && c->scanned) ? c->n_matches : 0; }
+
+int focr_get_matches(focr_ctx_t *c, uint64_t *offsets, focr_match_t *matches) {
+    if (!c) return FOCR_ERR_INVALID;
+    if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_get_matches: no scan results");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    if (offsets)
+        FOCR_HIP(c, hipMemcpyAsync(offsets, c->d_seg_offset, (c->n_pages * c->n_templates + 1) * 8, hipMemcpyDeviceToHost,
+                                   c->stream));
+    if (matches && c->n_matches)
+        FOCR_HIP(c, hipMemcpyAsync(matches, c->d_matches, c->n_matches * sizeof(focr_match_t), hipMemcpyDeviceToHost,
+                                   c->stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    return FOCR_OK;
+}
+
+int focr_last_timings(focr_ctx_t *c, float ms[6]) {
+    if (!c || !ms) return FOCR_ERR_INVALID;
+    for (int i = 0; i < 6; i++) ms[i] = c->ms[i];
+    return FOCR_OK;
+}
+
+int focr_last_counters(focr_ctx_t *c, uint64_t out[4]) {
+    if (!c || !out) return FOCR_ERR_INVALID;
+    for (int i = 0; i < 4; i++) out[i] = c->counters[i];
+    return FOCR_OK;
+}
+
+int focr_debug_rnorm(focr_ctx_t *c, const uint32_t *s, const uint64_t *s2, const uint32_t *n, size_t n_items, double *out) {
+    if (!c || !s || !s2 || !n || !out) return fail(c, FOCR_ERR_INVALID, "focr_debug_rnorm: bad arguments");
+    FOCR_HIP(c, hipSetDevice(c->device));
+    uint32_t *ds = nullptr, *dn = nullptr;
+    uint64_t *ds2 = nullptr;
+    double *dout = nullptr;
+    FOCR_HIP(c, hipMalloc(&ds, n_items * 4));
+    FOCR_HIP(c, hipMalloc(&dn, n_items * 4));
+    FOCR_HIP(c, hipMalloc(&ds2, n_items * 8));
+    FOCR_HIP(c, hipMalloc(&dout, n_items * 8));
+    FOCR_HIP(c, hipMemcpyAsync(ds, s, n_items * 4, hipMemcpyHostToDevice, c->stream));
+    FOCR_HIP(c, hipMemcpyAsync(dn, n, n_items * 4, hipMemcpyHostToDevice, c->stream));
+    FOCR_HIP(c, hipMemcpyAsync(ds2, s2, n_items * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(debug_rnorm_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream, ds, ds2, dn,
+                       n_items, dout);
+    FOCR_HIP(c, hipGetLastError());
+    FOCR_HIP(c, hipMemcpyAsync(out, dout, n_items * 8, hipMemcpyDeviceToHost, c->stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(ds);
+    (void)hipFree(dn);
+    (void)hipFree(ds2);
+    (void)hipFree(dout);
+    return FOCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// scan_direct.hip — exact evaluation of every (window, template) pair with v_dot4_u32_u8.
+//
+// This is the straightforward device formulation of the reference's hot loop
+// (src/ncc.cpp:302-392): one lane per window, the window's bytes held in
+// registers, every template of the size class streamed past it as scalar
+// operands, integer dot product by v_dot4_u32_u8, the f64 epilogue of
+// common.h, hits appended to an unordered list (ordering and the 1024 cap are
+// restored by order.hip).  Window statistics (patch_sum / patch_rnorm,
+// src/ncc.rs:306-312) are computed from the same registers, so this path needs
+// no summed-area tables at all.  It is the cross-check for the MFMA prefilter
+// path and the fallback for shapes that path does not cover.
+#include "common.h"
+
+namespace focr {
+
+constexpr int DTX = 64;  // windows per tile row (one wave)
+constexpr int DTY = 4;   // tile rows (waves per block)
+constexpr int DLDW = 21; // dwords per LDS tile row: covers byte columns [0, 84)
+
+template <int NDW, int MAXH>
+__global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restrict__ pages, uint32_t pitch,
+                                                          uint32_t rows_alloc, uint32_t r_w, uint32_t r_h, uint32_t n_w,
+                                                          uint32_t n_h, const uint32_t *__restrict__ bank,
+                                                          const TemplateConst *__restrict__ tc, uint32_t n_class,
+                                                          uint32_t n_total, double thr_d, uint64_t *__restrict__ hit_keys,
+                                                          float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
+                                                          unsigned long long capacity) {
+    constexpr int LROWS = DTY + MAXH - 1;
+    __shared__ uint32_t tile[LROWS][DLDW];
+    const uint32_t page = blockIdx.z;
+    const uint32_t x0 = blockIdx.x * DTX;      // byte column of LDS column 0 (dword aligned)
+    const uint32_t y0 = 1 + blockIdx.y * DTY;  // y = 0 is never searched (src/ncc.cpp:302)
+    const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
+    for (uint32_t i = threadIdx.x; i < LROWS * DLDW; i += 256) {
+        uint32_t r = i / DLDW, cdw = i % DLDW;
+        uint32_t gy = y0 + r, gx = x0 + cdw * 4;
+        uint32_t v = 0;
+        if (gy < rows_alloc && gx < pitch) v = *reinterpret_cast<const uint32_t *>(pg + (size_t)gy * pitch + gx);
+        tile[r][cdw] = v;
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const uint32_t x = x0 + 1 + lane, y = y0 + wy;  // x = 0 is never searched (src/ncc.rs:281)
+    const bool valid = (x + n_w <= r_w) && (y + n_h <= r_h);
+    const uint32_t col = 1 + lane, cb = col >> 2, sh = col & 3;
+
+    uint32_t win[MAXH][NDW];
+    uint32_t s_p = 0, s2_p = 0;
+#pragma unroll
+    for (int j = 0; j < MAXH; j++) {
+#pragma unroll
+        for (int k = 0; k < NDW; k++) {
+            uint32_t lo = tile[wy + j][cb + k], hi = tile[wy + j][cb + k + 1];
+            uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            // keep only the window's own n_w x n_h bytes
+            uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu
+                            : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
+            w = ((uint32_t)j < n_h) ? (w & keep) : 0u;
+            win[j][k] = w;
+            s_p = __builtin_amdgcn_udot4(w, 0x01010101u, s_p, false);
+            s2_p = __builtin_amdgcn_udot4(w, w, s2_p, false);
+        }
+    }
+    const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(n_w * n_h));
+    const uint64_t key_lo = ((uint64_t)y << 16) | (uint64_t)x;
+
+    for (uint32_t t = 0; t < n_class; t++) {
+        const uint32_t *tp = bank + (size_t)t * (MAXH * NDW);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < MAXH; j++)
+#pragma unroll
+            for (int k = 0; k < NDW; k++) acc = __builtin_amdgcn_udot4(win[j][k], tp[j * NDW + k], acc, false);
+        const double s_n = tc[t].s_n, n_recip = tc[t].n_recip, rnorm_n = tc[t].rnorm_n;
+        const double sim = ncc_similarity(acc, s_p, s_n, n_recip, rnorm_n, rnorm_p);
+        if (valid && ncc_emits(sim, thr_d)) {
+            unsigned long long idx = atomicAdd(counter, 1ull);
+            if (idx < capacity) {
+                hit_keys[idx] = ((uint64_t)(page * n_total + tc[t].index) << 32) | key_lo;
+                hit_sims[idx] = (float)sim;
+            }
+        }
+    }
+}
+
+template <int NDW, int MAXH>
+static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d) {
+    dim3 grid((unsigned)((c->r_w - sc.n_w + DTX - 1) / DTX), (unsigned)((c->r_h - sc.n_h + DTY - 1) / DTY),
+              (unsigned)c->n_pages);
+    hipLaunchKernelGGL((scan_direct_kernel<NDW, MAXH>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
+                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
+                       c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates,
+                       (uint32_t)c->n_templates, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
+                       (unsigned long long)c->hit_capacity);
+}
+
+int ensure_hit_capacity(focr_ctx *c, size_t want) {
+    if (c->hit_capacity >= want) return FOCR_OK;
+    if (want > ((size_t)1 << 33)) return fail(c, FOCR_ERR_OVERFLOW, "more than 2^33 raw hits in one batch; scan fewer pages per call");
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    for (void *p : {(void *)c->d_hit_keys, (void *)c->d_hit_keys_alt, (void *)c->d_hit_sims, (void *)c->d_hit_sims_alt})
+        if (p) (void)hipFree(p);
+    c->d_hit_keys = c->d_hit_keys_alt = nullptr;
+    c->d_hit_sims = c->d_hit_sims_alt = nullptr;
+    c->hit_capacity = 0;
+    if (hipMalloc(&c->d_hit_keys, want * 8) != hipSuccess || hipMalloc(&c->d_hit_keys_alt, want * 8) != hipSuccess ||
+        hipMalloc(&c->d_hit_sims, want * 4) != hipSuccess || hipMalloc(&c->d_hit_sims_alt, want * 4) != hipSuccess)
+        return fail(c, FOCR_ERR_NOMEM, "hit buffers: hipMalloc failed");
+    c->hit_capacity = want;
+    return FOCR_OK;
+}
+
+int launch_scan_direct(focr_ctx *c, float threshold) {
+    const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
+    int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->n_pages * 65536)));
+    if (rc) return rc;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
+        FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        for (size_t k = 0; k < c->classes.size(); k++) {
+            const SizeClass &sc = c->classes[k];
+            if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;  // no window with x,y >= 1 fits
+            switch (sc.ndw * 100 + sc.maxh) {
+                case 116: launch_one<1, 16>(c, sc, k, thr_d); break;
+                case 216: launch_one<2, 16>(c, sc, k, thr_d); break;
+                case 316: launch_one<3, 16>(c, sc, k, thr_d); break;
+                case 416: launch_one<4, 16>(c, sc, k, thr_d); break;
+                case 132: launch_one<1, 32>(c, sc, k, thr_d); break;
+                case 232: launch_one<2, 32>(c, sc, k, thr_d); break;
+                case 332: launch_one<3, 32>(c, sc, k, thr_d); break;
+                case 432: launch_one<4, 32>(c, sc, k, thr_d); break;
+                default: return fail(c, FOCR_ERR_INVALID, "scan_direct: unsupported size class");
+            }
+            FOCR_HIP(c, hipGetLastError());
+            c->counters[3] += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.ndw * 4 * sc.maxh * sc.n_templates * c->n_pages;
+        }
+        FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
+        FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
+        unsigned long long n = 0;
+        FOCR_HIP(c, hipMemcpyAsync(&n, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        c->n_hits_raw = n;
+        c->n_cand = n;
+        if (n <= c->hit_capacity) {
+            FOCR_HIP(c, hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]));
+            c->counters[0] = n;
+            c->counters[1] = n;
+            return FOCR_OK;
+        }
+        c->counters[3] = 0;
+        rc = ensure_hit_capacity(c, (size_t)n + (size_t)n / 8 + 1024);  // grow and rescan
+        if (rc) return rc;
+    }
+    return fail(c, FOCR_ERR_OVERFLOW, "scan_direct: hit buffer kept overflowing");
+}
+
+}  // namespace focr

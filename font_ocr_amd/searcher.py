@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's Searcher / get_hits / process_hits for the device path.
+
+Everything here is a thin ctypes call into libfocr_hip.so (include/focr_ncc.h).  Names follow the
+reference (src/ncc.rs): `Searcher.search_c_u8` is the per-template drop-in (FFI symbols
+ncc_8_u8 / ncc_16_u8), `Scanner` is the batched form of get_hits' search loop over resident pages,
+`process_hits` the anchor/line/overlap pass.  There is no CPU fallback: a missing library or
+device raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .bank import HIT_DTYPE, MATCH_DTYPE
+
+MAX_MATCHES = 1024  # src/ncc.rs:31
+SCAN_MFMA, SCAN_DIRECT = 0, 1
+
+
+class FocrError(RuntimeError):
+    pass
+
+
+def device_count():
+    return int(N.hip().focr_device_count())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Searcher:
+    """Per-page state of the reference (src/ncc.rs:128-141, 231-261) for the drop-in FFI symbols.
+
+    The caller supplies the window tables exactly as the reference's prepare_for_size produces
+    them (src/ncc.rs:263-318); search_c_u8 then does what src/ncc.rs:332-404 does, with the kernel
+    call landing on the GPU through the reference's own symbol names.
+    """
+
+    def __init__(self, page_inv):
+        self.reference_u8 = np.ascontiguousarray(page_inv, np.uint8)
+        r_h, r_w = self.reference_u8.shape
+        self.acc_u32 = np.zeros(r_w * 8 + 8, np.uint32)  # src/ncc.rs:242
+        self.matches_c = np.zeros(MAX_MATCHES, MATCH_DTYPE)  # src/ncc.rs:240
+
+    def search_c_u8(self, needle, stats, threshold, n_out=MAX_MATCHES):
+        """needle: (n_h, n_w) uint8; stats = (patch_sum, patch_rnorm, start_end).  Returns MATCH_DTYPE[]."""
+        lib = N.hip()
+        if lib.focr_device_count() <= 0:  # the FFI signature has no error channel: fail loudly here
+            raise FocrError("no HIP device available; the ncc_*_u8 symbols have no CPU fallback")
+        needle = np.ascontiguousarray(needle, np.uint8)
+        n_h, n_w = needle.shape
+        if n_w <= 8:  # src/ncc.rs:337
+            width, fn = 8, lib.ncc_8_u8
+        elif n_w <= 16:  # src/ncc.rs:364
+            width, fn = 16, lib.ncc_16_u8
+        else:
+            raise FocrError("not handled")  # panic!("not handled"), src/ncc.rs:392
+        padded = np.zeros((n_h, width), np.uint8)  # copy_needle_n_u8, src/ncc.rs:925-935
+        padded[:, :n_w] = needle
+        patch_sum, patch_rnorm, start_end = stats
+        patch_sum = np.ascontiguousarray(patch_sum, np.uint32)
+        patch_rnorm = np.ascontiguousarray(patch_rnorm, np.float64)
+        start_end = np.ascontiguousarray(start_end, np.uint16)
+        r_h, r_w = self.reference_u8.shape
+        out = self.matches_c if n_out == MAX_MATCHES else np.zeros(n_out, MATCH_DTYPE)
+        n = fn(_ptr(self.reference_u8), r_w, r_h, _ptr(padded), n_w, n_h, _ptr(self.acc_u32), self.acc_u32.size,
+               _ptr(patch_sum), _ptr(patch_rnorm), _ptr(start_end), float(threshold), _ptr(out), n_out)
+        return out[:n].copy()
+
+
+class Scanner:
+    """Batched device scan: one bank, N resident pages (get_hits' loop, src/ncc.rs:576-701)."""
+
+    def __init__(self, device=0):
+        self._lib = N.hip()
+        h = C.c_void_p()
+        rc = self._lib.focr_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise FocrError(self._lib.focr_last_error_global().decode())
+        self._h = h
+        self.bank = None
+        self.n_pages = self.r_w = self.r_h = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.focr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise FocrError(f"[{rc}] " + self._lib.focr_last_error(self._h).decode())
+
+    def set_bank(self, bank):
+        self._ck(self._lib.focr_bank_upload(self._h, _ptr(bank.templates), len(bank.templates), _ptr(bank.needles),
+                                            bank.needles.size))
+        self.bank = bank
+
+    def alloc_pages(self, n_pages, r_w, r_h):
+        self._ck(self._lib.focr_pages_alloc(self._h, n_pages, r_w, r_h))
+        self.n_pages, self.r_w, self.r_h = n_pages, r_w, r_h
+
+    def upload_pages(self, luma, first=0, invert=True):
+        """luma: (n, r_h, r_w) uint8 as the image decoder gives it (255 = paper)."""
+        luma = np.ascontiguousarray(luma, np.uint8)
+        if luma.ndim == 2:
+            luma = luma[None]
+        assert luma.shape[1:] == (self.r_h, self.r_w)
+        self._ck(self._lib.focr_pages_upload(self._h, first, luma.shape[0], _ptr(luma), int(bool(invert))))
+
+    def upload_pages_device(self, dev_ptr, count, first=0, invert=True):
+        """Pages already in HBM (e.g. tensor.data_ptr() of a uint8 CUDA tensor)."""
+        self._ck(self._lib.focr_pages_upload_device(self._h, first, count, C.c_void_p(int(dev_ptr)), int(bool(invert))))
+
+    def set_pages(self, luma, invert=True):
+        luma = np.ascontiguousarray(luma, np.uint8)
+        if luma.ndim == 2:
+            luma = luma[None]
+        self.alloc_pages(luma.shape[0], luma.shape[2], luma.shape[1])
+        self.upload_pages(luma, 0, invert)
+
+    def scan(self, threshold=0.8, cap=MAX_MATCHES, mode=SCAN_MFMA):
+        self._ck(self._lib.focr_scan(self._h, float(threshold), int(cap), int(mode)))
+
+    def sync(self):
+        self._ck(self._lib.focr_sync(self._h))
+
+    def counts(self):
+        out = np.zeros((self.n_pages, len(self.bank)), np.uint32)
+        self._ck(self._lib.focr_get_counts(self._h, _ptr(out)))
+        return out
+
+    def total_matches(self):
+        return int(self._lib.focr_total_matches(self._h))
+
+    def matches(self):
+        """(offsets[n_pages*T+1], matches[total]) in (page, template, y, x) order."""
+        n_seg = self.n_pages * len(self.bank)
+        offsets = np.zeros(n_seg + 1, np.uint64)
+        m = np.zeros(self.total_matches(), MATCH_DTYPE)
+        self._ck(self._lib.focr_get_matches(self._h, _ptr(offsets), _ptr(m)))
+        return offsets, m
+
+    def process_hits(self, anchor_threshold=0.95, overlap=5):
+        self._ck(self._lib.focr_process_hits(self._h, float(anchor_threshold), int(overlap)))
+
+    def lines(self):
+        """-> list over pages of list over lines of HIT_DTYPE arrays."""
+        n_lines = int(self._lib.focr_total_lines(self._h))
+        n_chars = int(self._lib.focr_total_chars(self._h))
+        page_off = np.zeros(self.n_pages + 1, np.uint64)
+        line_off = np.zeros(n_lines + 1, np.uint64)
+        chars = np.zeros(n_chars, HIT_DTYPE)
+        self._ck(self._lib.focr_get_lines(self._h, _ptr(page_off), _ptr(line_off), _ptr(chars)))
+        out = []
+        for p in range(self.n_pages):
+            out.append([chars[int(line_off[k]): int(line_off[k + 1])] for k in range(int(page_off[p]), int(page_off[p + 1]))])
+        return out
+
+    def timings(self):
+        ms = (C.c_float * 6)()
+        self._lib.focr_last_timings(self._h, ms)
+        return dict(zip(("stats", "scan", "verify", "order", "process_hits", "total"), [float(v) for v in ms]))
+
+    def counters(self):
+        c = (C.c_uint64 * 4)()
+        self._lib.focr_last_counters(self._h, c)
+        return dict(zip(("candidates", "raw_hits", "algorithmic_macs", "issued_macs"), [int(v) for v in c]))
+
+    def debug_rnorm(self, s, s2, n):
+        s = np.ascontiguousarray(s, np.uint32)
+        s2 = np.ascontiguousarray(s2, np.uint64)
+        n = np.ascontiguousarray(n, np.uint32)
+        out = np.zeros(len(s), np.float64)
+        self._ck(self._lib.focr_debug_rnorm(self._h, _ptr(s), _ptr(s2), _ptr(n), len(s), _ptr(out)))
+        return out
+
+
+def text_of(lines):
+    """Default `ncc` output of one page: letters of each line concatenated (src/ncc.rs:869-876)."""
+    return "\n".join("".join(chr(int(c)) for c in line["letter"]) for line in lines)

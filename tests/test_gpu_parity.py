@@ -1,0 +1,206 @@
+"""Parity of the HIP path (through the C ABI) against the oracle / the reference's golden vectors.
+Bit-exact: x, y and the f32 similarity bits, including order and the 1024 cap."""
+import numpy as np
+import pytest
+
+from font_ocr_amd import synth_page, synth_pages
+from font_ocr_amd.bank import SYNTH_SEED_BASE
+from font_ocr_amd.searcher import SCAN_DIRECT, SCAN_MFMA, Scanner, Searcher, text_of
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODES = [pytest.param(SCAN_DIRECT, id="direct"), pytest.param(SCAN_MFMA, id="mfma")]
+
+
+@pytest.fixture(scope="module")
+def scanner():
+    s = Scanner(0)
+    yield s
+    s.close()
+
+
+def _csr_to_lists(offsets, m, n_pages, T):
+    return [[m[int(offsets[p * T + t]): int(offsets[p * T + t + 1])] for t in range(T)] for p in range(n_pages)]
+
+
+def _oracle_lists(pages_luma, bank, thr, cap, use_ref=None):
+    use_ref = O.have_ref() if use_ref is None else use_ref
+    out = []
+    for pg in pages_luma:
+        counts, matches = O.scan_page(O.invert(pg), bank, thr, cap, use_ref=use_ref)
+        out.append([matches[t, : counts[t]] for t in range(len(counts))])
+    return out
+
+
+def _assert_same(got, want, what=""):
+    for p, (gp, wp) in enumerate(zip(got, want)):
+        for t, (g, w) in enumerate(zip(gp, wp)):
+            assert len(g) == len(w), f"{what} page {p} template {t}: {len(g)} != {len(w)}"
+            assert g.tobytes() == w.tobytes(), f"{what} page {p} template {t}"
+
+
+def test_device_f64_divide_sqrt_are_correctly_rounded(scanner):
+    """patch_rnorm (src/ncc.rs:309-311) on the device == host IEEE, bit for bit, on 4e6 triples."""
+    rng = np.random.default_rng(1)
+    cnt = 4_000_000
+    n = rng.integers(1, 257, cnt).astype(np.uint32)
+    mean = rng.integers(0, 256, cnt).astype(np.uint64)
+    s = (mean * n + rng.integers(0, 200, cnt).astype(np.uint64)).astype(np.uint32)
+    var = rng.integers(0, 2_000_000, cnt).astype(np.uint64)
+    var[rng.random(cnt) < 0.1] = 0
+    s2 = (s.astype(np.uint64) ** 2) // n + var  # any s2 >= ~s^2/n, including exact-zero variance
+    got = scanner.debug_rnorm(s, s2, n)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = 1.0 / np.sqrt(s2.astype(np.float64) - (s.astype(np.uint64) * s.astype(np.uint64)).astype(np.float64) / n.astype(np.float64))
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"{(~same).sum()} of {cnt} differ"
+
+
+def test_compat_symbols_on_golden_vectors(kernel_cases):
+    """ncc_8_u8 / ncc_16_u8 (the reference's FFI names) == the reference kernel's committed outputs."""
+    for name, c in kernel_cases.items():
+        s = Searcher(c["page"])
+        got = s.search_c_u8(c["needle"], (c["patch_sum"], c["patch_rnorm"], c["start_end"]), float(c["thr"]), int(c["cap"]))
+        assert got.tobytes() == c["expect"].tobytes(), name
+        assert not s.acc_u32.any()
+
+
+def test_compat_symbols_random_vs_oracle():
+    rng = np.random.default_rng(11)
+    for it in range(25):
+        r_w, r_h = int(rng.integers(20, 300)), int(rng.integers(20, 120))
+        n_w, n_h = int(rng.integers(1, 17)), int(rng.integers(1, 19))
+        page = rng.integers(0, 256, (r_h, r_w), dtype=np.uint8)
+        if it % 3 == 0:
+            page[rng.random((r_h, r_w)) < 0.9] = 0
+        y0, x0 = int(rng.integers(0, r_h - n_h + 1)), int(rng.integers(0, r_w - n_w + 1))
+        nd = page[y0:y0 + n_h, x0:x0 + n_w].copy() if it % 2 else rng.integers(0, 256, (n_h, n_w), dtype=np.uint8)
+        thr = float(rng.choice([-1.0, 0.0, 0.3, 0.8]))
+        cap = int(rng.choice([1, 5, 1024]))
+        stats = O.prepare_for_size(page, n_w, n_h)
+        want = O.ncc_u8(O.padded(page), r_w, r_h, nd, stats, thr, cap, use_ref=O.have_ref())
+        got = Searcher(page).search_c_u8(nd, stats, thr, cap)
+        assert got.tobytes() == want.tobytes(), (it, r_w, r_h, n_w, n_h, thr, cap)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_c1_page_matches_reference_lists(scanner, bank_default, c1_golden, mode):
+    """configs[0]: 608x720 page, 74 templates — raw lists == reference kernel, lines == oracle."""
+    scanner.set_bank(bank_default)
+    scanner.set_pages(c1_golden["page"])
+    scanner.scan(0.8, 1024, mode)
+    counts = scanner.counts()[0]
+    assert np.array_equal(counts, c1_golden["counts"])
+    offsets, m = scanner.matches()
+    assert m.tobytes() == c1_golden["matches"].tobytes()
+    assert np.array_equal(np.diff(offsets.astype(np.int64)), counts)
+    scanner.process_hits(0.95, 5)
+    lines = scanner.lines()[0]
+    flat = np.concatenate(lines)
+    g = c1_golden["lines"]
+    assert len(flat) == len(g)
+    for f in ("x", "y", "w", "h", "letter"):
+        assert np.array_equal(flat[f].astype(np.int64), g[f].astype(np.int64)), f
+    assert flat["similarity"].tobytes() == g["similarity"].tobytes()
+    assert np.array_equal(np.cumsum([len(l) for l in lines]), c1_golden["line_ends"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_c2_page0_matches_reference_lists(scanner, bank_x2, c2_golden, mode):
+    """configs[1] bank (95 glyphs x 4 x-shifts = 380 templates, two size classes) on page 0."""
+    page = synth_page(bank_x2, SYNTH_SEED_BASE, 608, 720)
+    scanner.set_bank(bank_x2)
+    scanner.set_pages(page)
+    scanner.scan(0.8, 1024, mode)
+    assert np.array_equal(scanner.counts()[0], c2_golden["counts"])
+    _, m = scanner.matches()
+    assert m.tobytes() == c2_golden["matches"].tobytes()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("thr,cap", [(0.8, 1024), (0.3, 1024), (-1.0, 1024), (0.0, 3), (0.999, 1024)])
+def test_small_batch_vs_oracle(scanner, bank_x2, mode, thr, cap):
+    """Several small pages, a 40-template slice of the bank with both size classes, incl. the cap."""
+    idx = list(range(30, 50)) + list(range(95 + 30, 95 + 50))
+    bank = bank_x2.subset(idx)
+    pages = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 100 + p, 160, 80) for p in range(3)])
+    pages[2, :, :] = 255  # a blank page in the batch
+    pages[1, 40:, 100:] = 0  # a saturated block
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    scanner.scan(thr, cap, mode)
+    offsets, m = scanner.matches()
+    got = _csr_to_lists(offsets, m, 3, len(bank))
+    want = _oracle_lists(pages, bank, thr, cap)
+    _assert_same(got, want, f"thr={thr} cap={cap}")
+    assert np.array_equal(scanner.counts(), np.array([[len(x) for x in p] for p in want], np.uint32))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_ragged_and_degenerate_pages(scanner, bank_x2, mode):
+    """Odd page sizes (not multiples of any tile), pages barely larger than a template, noise pages."""
+    rng = np.random.default_rng(5)
+    bank = bank_x2.subset([33, 34, 95 + 33, 2 * 95 + 40])
+    for (w, h) in [(9, 16), (10, 16), (17, 17), (65, 21), (130, 33), (257, 19)]:
+        pages = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+        pages[1][rng.random((h, w)) < 0.8] = 255
+        scanner.set_bank(bank)
+        scanner.set_pages(pages)
+        scanner.scan(0.2, 1024, mode)
+        offsets, m = scanner.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), _oracle_lists(pages, bank, 0.2, 1024), f"{w}x{h}")
+        scanner.process_hits(0.5, 5)  # must not fail on sparse / empty results
+        scanner.lines()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_process_hits_vs_oracle_on_batch(scanner, bank_x2, mode):
+    pages = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 200 + p, 400, 150) for p in range(4)])
+    scanner.set_bank(bank_x2)
+    scanner.set_pages(pages)
+    scanner.scan(0.8, 1024, mode)
+    offsets, m = scanner.matches()
+    got = _csr_to_lists(offsets, m, 4, len(bank_x2))
+    for anchor, overlap in [(0.95, 5), (0.9, 0), (0.99, 12)]:
+        scanner.process_hits(anchor, overlap)
+        lines = scanner.lines()
+        for p in range(4):
+            counts = np.array([len(x) for x in got[p]], np.uint32)
+            mm = np.zeros((len(bank_x2), 1024), O.MATCH_DTYPE)
+            for t, x in enumerate(got[p]):
+                mm[t, : len(x)] = x
+            want = O.process_hits(O.raw_hits(counts, mm, bank_x2), anchor, overlap)
+            assert len(lines[p]) == len(want), (p, anchor, overlap)
+            for lg, lw in zip(lines[p], want):
+                assert np.array_equal(lg["x"].astype(np.int64), lw["x"].astype(np.int64))
+                assert np.array_equal(lg["y"].astype(np.int64), lw["y"].astype(np.int64))
+                assert np.array_equal(lg["letter"], lw["letter"])
+                assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
+
+
+def test_full_size_c2_properties(scanner, bank_x2):
+    """BASELINE configs[1] at full size (128 pages 608x720, 380 templates): size-independent checks —
+    direct and MFMA paths agree on every list, the first page equals the reference golden, and the
+    stamped text comes back."""
+    n_pages = 128
+    pages = synth_pages(bank_x2, n_pages, 608, 720)
+    scanner.set_bank(bank_x2)
+    scanner.set_pages(pages)
+    res = {}
+    for mode in (SCAN_DIRECT, SCAN_MFMA):
+        scanner.scan(0.8, 1024, mode)
+        res[mode] = (scanner.counts().copy(),) + scanner.matches()
+    assert np.array_equal(res[SCAN_DIRECT][0], res[SCAN_MFMA][0])
+    assert res[SCAN_DIRECT][2].tobytes() == res[SCAN_MFMA][2].tobytes()
+    scanner.process_hits(0.95, 5)
+    lines = scanner.lines()
+    ok = tot = 0
+    for p in (0, 17, 127):
+        _, truth = synth_page(bank_x2, SYNTH_SEED_BASE + p, 608, 720, with_truth=True)
+        by_y = {int(l[0]["y"]): "".join(chr(int(c)) for c in l["letter"]) for l in lines[p]}
+        for y in sorted(set(truth["y"].tolist())):
+            want = "".join(chr(int(c)) for c in truth[truth["y"] == y]["letter"])
+            ok += by_y.get(y) == want
+            tot += 1
+    assert ok >= 0.9 * tot, (ok, tot)
