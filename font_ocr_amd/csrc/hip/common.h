@@ -60,7 +60,10 @@ struct focr_ctx {
     focr::TemplateConst *d_tconst = nullptr;    // class-ordered
     uint32_t *d_direct_bank = nullptr;          // class-ordered, [maxh][ndw] dwords each
     std::vector<size_t> direct_bank_off;        // dword offset per class
-    int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter
+    int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
+    uint32_t *d_tglobal = nullptr;              // class-ordered -> global template index, 0xffffffff = never emits
+    uint32_t *d_order_of = nullptr;             // global template index -> class-ordered index
+    std::vector<double> mfma_c_scale, mfma_e_max;  // per class: quantisation scale, max rounding-error norm
     uint8_t *d_needles = nullptr;               // dense needles (class-ordered, for verify)
     std::vector<uint32_t> h_needle_off;         // class-ordered byte offsets into d_needles
     uint32_t *d_needle_off = nullptr;

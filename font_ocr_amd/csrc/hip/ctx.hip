@@ -49,6 +49,10 @@ static void free_bank(focr_ctx *c) {
     free_dev(c->d_tconst);
     free_dev(c->d_direct_bank);
     free_dev(c->d_qbank);
+    free_dev(c->d_tglobal);
+    free_dev(c->d_order_of);
+    c->mfma_c_scale.clear();
+    c->mfma_e_max.clear();
     free_dev(c->d_needles);
     free_dev(c->d_needle_off);
     free_dev(c->d_t_w);
