@@ -63,6 +63,13 @@ class BankStruct(C.Structure):
     ]
 
 
+class LaunchInfo(C.Structure):
+    """focr_launch_info_t (include/focr_ncc.h)."""
+
+    _fields_ = [("name", C.c_char * 64), ("ms", C.c_float), ("n_templates", C.c_uint32), ("alg_macs", C.c_uint64),
+                ("issued_macs", C.c_uint64)]
+
+
 _NCC_ARGS = [
     C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
     C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
@@ -92,6 +99,7 @@ HIP_SYMBOLS = {
     "focr_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_last_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_sync": (C.c_int, [C.c_void_p]),
+    "focr_last_launches": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_debug_rnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

@@ -108,6 +108,14 @@ struct focr_ctx {
     hipEvent_t ev[8] = {};
     float ms[6] = {};
     uint64_t counters[4] = {};
+
+    // per-launch timing of the scan kernels (focr_last_launches)
+    std::vector<focr_launch_info_t> launches;
+    std::vector<hipEvent_t> launch_events;  // pool, two per launch
+    void launch_begin(const char *name, uint32_t n_templates, uint64_t alg, uint64_t issued);
+    void launch_end();
+    void launches_reset() { launches.clear(); }
+    void launches_collect();  // after a stream sync: fill ms
 };
 
 namespace focr {

@@ -87,7 +87,35 @@ static void free_results(focr_ctx *c) {
 
 using namespace focr;
 
+void focr_ctx::launch_begin(const char *name, uint32_t n_t, uint64_t alg, uint64_t issued) {
+    focr_launch_info_t li{};
+    snprintf(li.name, sizeof li.name, "%s", name);
+    li.n_templates = n_t;
+    li.alg_macs = alg;
+    li.issued_macs = issued;
+    launches.push_back(li);
+    while (launch_events.size() < 2 * launches.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        launch_events.push_back(e);
+    }
+    (void)hipEventRecord(launch_events[2 * (launches.size() - 1)], stream);
+}
+
+void focr_ctx::launch_end() { (void)hipEventRecord(launch_events[2 * (launches.size() - 1) + 1], stream); }
+
+void focr_ctx::launches_collect() {
+    for (size_t i = 0; i < launches.size(); i++)
+        if (hipEventElapsedTime(&launches[i].ms, launch_events[2 * i], launch_events[2 * i + 1]) != hipSuccess) launches[i].ms = 0.f;
+}
+
 extern "C" {
+
+size_t focr_last_launches(focr_ctx_t *c, focr_launch_info_t *out, size_t cap) {
+    if (!c) return 0;
+    for (size_t i = 0; out && i < c->launches.size() && i < cap; i++) out[i] = c->launches[i];
+    return c->launches.size();
+}
 
 const char *focr_last_error_global(void) {
     static thread_local std::string copy;
@@ -135,6 +163,8 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     free_dev(c->d_stage);
     free_dev(c->d_counter);
     for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->launch_events)
         if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

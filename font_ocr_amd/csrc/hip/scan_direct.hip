@@ -88,11 +88,16 @@ template <int NDW, int MAXH>
 static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d) {
     dim3 grid((unsigned)((c->r_w - sc.n_w + DTX - 1) / DTX), (unsigned)((c->r_h - sc.n_h + DTY - 1) / DTY),
               (unsigned)c->n_pages);
+    const uint64_t win = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * c->n_pages;
+    char name[64];
+    snprintf(name, sizeof name, "scan_direct_kernel<%d,%d>", NDW, MAXH);
+    c->launch_begin(name, sc.n_templates, win * sc.n_w * sc.n_h * sc.n_templates, win * NDW * 4 * MAXH * sc.n_templates);
     hipLaunchKernelGGL((scan_direct_kernel<NDW, MAXH>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
                        c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates,
                        (uint32_t)c->n_templates, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
                        (unsigned long long)c->hit_capacity);
+    c->launch_end();
 }
 
 int ensure_hit_capacity(focr_ctx *c, size_t want) {
@@ -116,6 +121,7 @@ int launch_scan_direct(focr_ctx *c, float threshold) {
     int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->n_pages * 65536)));
     if (rc) return rc;
     for (int attempt = 0; attempt < 3; attempt++) {
+        c->launches_reset();
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
@@ -147,6 +153,7 @@ int launch_scan_direct(focr_ctx *c, float threshold) {
             FOCR_HIP(c, hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]));
             c->counters[0] = n;
             c->counters[1] = n;
+            c->launches_collect();
             return FOCR_OK;
         }
         c->counters[3] = 0;

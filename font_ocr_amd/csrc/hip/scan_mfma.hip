@@ -95,6 +95,18 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // 2. MFMA prefilter
+constexpr uint32_t WBUF = 64;  // wave-private candidate staging entries in LDS (no atomics on the way in)
+
+// one global atomic per flush: lane 0 reserves `count` slots, the wave copies its staged keys out coalesced
+__device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t count, int lane, uint64_t *__restrict__ cand,
+                                                      unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cand_counter, (unsigned long long)count);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)hi << 32) | lo;
+    if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
+}
+
 template <int KSTEPS, int RPG, int MT>
 __global__ __launch_bounds__(512, 4) void scan_mfma_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t tiles_x, uint32_t tiles_y,
@@ -112,6 +124,8 @@ __global__ __launch_bounds__(512, 4) void scan_mfma_kernel(
     for (uint32_t i = threadIdx.x; i < bank_vec; i += 512) bank[i] = qbank[i];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    uint64_t *wbuf = reinterpret_cast<uint64_t *>(tile + ((TROWS * MPITCH + 15) & ~15)) + w * WBUF;
+    uint32_t wcount = 0;  // wave-uniform number of staged candidates
     const uint32_t total_tiles = n_pages * tiles_y * tiles_x;
 
     for (uint32_t tid = blockIdx.x; tid < total_tiles; tid += gridDim.x) {
@@ -178,21 +192,29 @@ __global__ __launch_bounds__(512, 4) void scan_mfma_kernel(
             if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform, rare
                 const uint32_t tl = nt * 16 + r;
                 const uint32_t tg = tl < n_chunk ? tglobal[tl] : 0xffffffffu;  // dead / padding templates never emit
-                if (tg != 0xffffffffu && m > 0) {
+                const bool lane_ok = tg != 0xffffffffu;
+                const uint64_t key_hi = ((uint64_t)(page * n_total + tg) << 32) | ((uint64_t)y << 16);
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
+                for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (acc[mt][i] > 0) {
-                                const uint32_t x = x0 + 16 * mt + 4 * g + i;
-                                unsigned long long idx = atomicAdd(cand_counter, 1ull);
-                                if (idx < cand_cap)
-                                    cand[idx] = ((uint64_t)(page * n_total + tg) << 32) | ((uint64_t)y << 16) | (uint64_t)x;
+                    for (int i = 0; i < 4; i++) {
+                        const bool f = lane_ok && acc[mt][i] > 0;
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(f);
+                        if (mask) {  // wave-uniform
+                            const uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
+                            if (wcount + cnt > WBUF) {
+                                flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                                wcount = 0;
                             }
-                }
+                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (f) wbuf[wcount + pos] = key_hi | (uint64_t)(x0 + 16 * mt + 4 * g + i);
+                            wcount += cnt;
+                        }
+                    }
             }
         }
     }
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -349,17 +371,24 @@ static void launch_mfma(focr_ctx *c, const MfmaLaunch &L, unsigned n_blocks) {
     const uint32_t tiles_x = (uint32_t)((c->r_w - sc.n_w + 1 + twid - 1) / twid);  // windows x in [0, r_w - n_w]
     const uint32_t tiles_y = (uint32_t)((c->r_h - sc.n_h + 1 + MWAVES - 1) / MWAVES);
     const uint32_t n_tiles16 = (L.chunk_n + 15) / 16;
-    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)(MWAVES + 4 * KSTEPS * RPG - 1) * MPITCH;
+    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (((size_t)(MWAVES + 4 * KSTEPS * RPG - 1) * MPITCH + 15) & ~(size_t)15) +
+                       (size_t)MWAVES * WBUF * 8;
     const uint64_t total_tiles = (uint64_t)tiles_x * tiles_y * c->n_pages;
     unsigned grid = (unsigned)std::min<uint64_t>(n_blocks, total_tiles);
     auto kern = scan_mfma_kernel<KSTEPS, RPG, MT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + sc.q_offset + (size_t)(L.chunk_first / 16) * KSTEPS * 1024);
+    const uint64_t issued = total_tiles * MWAVES * twid * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
+    const uint64_t alg = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * L.chunk_n * c->n_pages;
+    char name[64];
+    snprintf(name, sizeof name, "scan_mfma_kernel<%d,%d,%d>", KSTEPS, RPG, MT);
+    c->launch_begin(name, L.chunk_n, alg, issued);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        tiles_x, tiles_y, (uint32_t)c->n_pages, qb, n_tiles16, L.chunk_n, L.negL, L.Lpitch, L.Lrows,
                        c->d_tglobal + sc.first + L.chunk_first, (uint32_t)c->n_templates, c->d_cand,
                        (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
-    c->counters[3] += total_tiles * MWAVES * twid * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
+    c->launch_end();
+    c->counters[3] += issued;
 }
 
 static int dispatch_mfma(focr_ctx *c, const MfmaLaunch &L, unsigned n_blocks) {
@@ -408,6 +437,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             c->cand_capacity = want_cand;
         }
         c->counters[3] = 0;
+        c->launches_reset();
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // 1. statistics
@@ -471,6 +501,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[3]));
         c->counters[0] = n_cand;
         c->counters[1] = n_hits;
+        c->launches_collect();
         return FOCR_OK;
     }
     return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: candidate buffer kept overflowing");

@@ -169,6 +169,16 @@ class Scanner:
             out.append([chars[int(line_off[k]): int(line_off[k + 1])] for k in range(int(page_off[p]), int(page_off[p + 1]))])
         return out
 
+    def lines_flat(self):
+        """All post-processed characters of the batch as one HIT_DTYPE array (page, line, x order)."""
+        n_chars = int(self._lib.focr_total_chars(self._h))
+        chars = np.zeros(n_chars, HIT_DTYPE)
+        self._ck(self._lib.focr_get_lines(self._h, None, None, _ptr(chars)))
+        return chars
+
+    def total_chars(self):
+        return int(self._lib.focr_total_chars(self._h))
+
     def timings(self):
         ms = (C.c_float * 6)()
         self._lib.focr_last_timings(self._h, ms)
@@ -178,6 +188,14 @@ class Scanner:
         c = (C.c_uint64 * 4)()
         self._lib.focr_last_counters(self._h, c)
         return dict(zip(("candidates", "raw_hits", "algorithmic_macs", "issued_macs"), [int(v) for v in c]))
+
+    def launches(self):
+        """Per-launch records of the last scan's scan kernels: list of dicts (name, ms, n_templates, macs)."""
+        n = int(self._lib.focr_last_launches(self._h, None, 0))
+        arr = (N.LaunchInfo * max(n, 1))()
+        self._lib.focr_last_launches(self._h, arr, n)
+        return [dict(name=arr[i].name.decode(), ms=float(arr[i].ms), n_templates=int(arr[i].n_templates),
+                     alg_macs=int(arr[i].alg_macs), issued_macs=int(arr[i].issued_macs)) for i in range(n)]
 
     def debug_rnorm(self, s, s2, n):
         s = np.ascontiguousarray(s, np.uint32)

@@ -180,6 +180,20 @@ int focr_last_timings(focr_ctx_t *ctx, float ms[6]);
 int focr_last_counters(focr_ctx_t *ctx, uint64_t c[4]);
 int focr_sync(focr_ctx_t *ctx);
 
+/* Per-launch record of the scan kernels of the last focr_scan (one entry per
+ * (size class, bank chunk) launch), timed with HIP events on the stream the
+ * kernel ran on.  alg_macs: true template area x searched windows x templates
+ * of that launch; issued_macs: MACs the launch issued including padding. */
+typedef struct focr_launch_info {
+    char name[64];
+    float ms;
+    uint32_t n_templates;
+    uint64_t alg_macs;
+    uint64_t issued_macs;
+} focr_launch_info_t;
+/* Copies up to cap records, returns the number of launches of the last scan. */
+size_t focr_last_launches(focr_ctx_t *ctx, focr_launch_info_t *out, size_t cap);
+
 /* Device self-test hook used by the parity tests: evaluates
  * 1/sqrt((double)s2 - (double)(s*s)/(double)n) on the device for n_items
  * triples, so the f64 divide/sqrt rounding can be compared with the host's. */
