@@ -215,6 +215,16 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
         members[k].push_back((uint32_t)t);
     }
 
+    // Inside a class, order templates by (letter, shift): the sub-pixel variants of one glyph fire on the
+    // same windows, so they should share a 16-template MFMA N-tile (fewer prefilter slow-path visits).
+    // Results are keyed by the global template index, so this order is invisible to callers.
+    for (auto &mem : members)
+        std::stable_sort(mem.begin(), mem.end(), [&](uint32_t a, uint32_t b) {
+            if (templates[a].letter != templates[b].letter) return templates[a].letter < templates[b].letter;
+            if (templates[a].shift_x != templates[b].shift_x) return templates[a].shift_x < templates[b].shift_x;
+            return templates[a].shift_y < templates[b].shift_y;
+        });
+
     std::vector<uint32_t> direct;
     std::vector<uint8_t> dense;
     uint32_t first = 0;

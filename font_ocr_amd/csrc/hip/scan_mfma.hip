@@ -29,15 +29,12 @@
 #include <cmath>
 #include <cstring>
 
-#include "common.h"
+#include "mfma_common.h"
 
 namespace focr {
 
 int ensure_hit_capacity(focr_ctx *c, size_t want);
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-constexpr int32_t REJECT = 0x3fffffff;
 constexpr int MWAVES = 8;                 // window rows (= waves) per block tile
 constexpr int MPITCH = 96;                // LDS image-tile pitch in bytes (24 dwords: conflict-free A reads)
 constexpr size_t BANK_LDS_BUDGET = 72 << 10;  // bytes of LDS per block for the bank chunk (2 blocks / CU)
@@ -95,18 +92,6 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // 2. MFMA prefilter
-constexpr uint32_t WBUF = 64;  // wave-private candidate staging entries in LDS (no atomics on the way in)
-
-// one global atomic per flush: lane 0 reserves `count` slots, the wave copies its staged keys out coalesced
-__device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t count, int lane, uint64_t *__restrict__ cand,
-                                                      unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(cand_counter, (unsigned long long)count);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    base = ((unsigned long long)hi << 32) | lo;
-    if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
-}
-
 template <int KSTEPS, int RPG, int MT>
 __global__ __launch_bounds__(512, 4) void scan_mfma_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t tiles_x, uint32_t tiles_y,
@@ -357,13 +342,6 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kappa, negL, Lpitch, Lrows);
 }
 
-struct MfmaLaunch {
-    const SizeClass *sc;
-    uint32_t chunk_first, chunk_n;  // templates of the class covered by this launch (multiple of 16 except the last)
-    const int32_t *negL;
-    uint32_t Lpitch, Lrows;
-};
-
 template <int KSTEPS, int RPG, int MT>
 static void launch_mfma(focr_ctx *c, const MfmaLaunch &L, unsigned n_blocks) {
     const SizeClass &sc = *L.sc;
@@ -426,6 +404,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     hipDeviceProp_t prop;
     FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
     const unsigned n_blocks = 2u * (unsigned)prop.multiProcessorCount;
+    int variant = 2;  // FOCR_MFMA_VARIANT=1 selects the LDS-tiled, barrier-per-tile kernel (kept for A/B)
+    if (const char *e = getenv("FOCR_MFMA_VARIANT")) variant = atoi(e) == 1 ? 1 : 2;
 
     for (int attempt = 0; attempt < 4; attempt++) {
         if (c->cand_capacity < want_cand) {
@@ -466,10 +446,12 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const SizeClass &sc = c->classes[k];
             if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
             const uint32_t ksteps = sc.k_groups / 4;
-            const uint32_t chunk_max = (uint32_t)(BANK_LDS_BUDGET / (ksteps * 1024)) * 16;
+            const size_t budget = variant == 1 ? BANK_LDS_BUDGET : mfma2_bank_budget();
+            const uint32_t chunk_max = (uint32_t)(budget / (ksteps * 1024)) * 16;
             for (uint32_t first = 0; first < sc.n_templates; first += chunk_max) {
                 MfmaLaunch L{&sc, first, std::min(chunk_max, sc.n_templates - first), c->d_L + k * L_per_class, Lpitch, Lrows};
-                if ((rc = dispatch_mfma(c, L, n_blocks))) return rc;
+                rc = variant == 1 ? dispatch_mfma(c, L, n_blocks) : dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount);
+                if (rc) return rc;
             }
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));

@@ -1,0 +1,211 @@
+// scan_mfma2.hip — barrier-free i8 MFMA prefilter (default variant).
+//
+// Same arithmetic and B-operand layout as scan_mfma.hip (see its header for the maths); what
+// changes is who feeds the A operand.  Here every wave is an independent worker: it takes MT
+// consecutive 16-window M-tiles of the (page, row, column) enumeration, reads its A fragments
+// straight from the page in HBM/L2 (two aligned loads + v_alignbyte per 16-byte k-group; the page
+// is read ~16x per class, all but the first time from L2), and streams the whole quantised bank
+// chunk past them from LDS.  The bank is staged once per block, so the kernel has exactly one
+// barrier; there is no per-tile fill/drain, and with 128 windows per wave a B fragment (1 KiB
+// ds_read_b128) feeds 8 MFMAs.  One 512-thread block per CU, 2 waves per SIMD, <= 256 VGPRs.
+#include <algorithm>
+
+#include "mfma_common.h"
+
+namespace focr {
+
+typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned views: gfx950 global loads take any alignment
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef v2i v2i_u __attribute__((aligned(1)));
+
+constexpr int V2_WAVES = 8;
+constexpr size_t V2_BANK_BUDGET = 136 << 10;  // one block per CU: the rest of the 160 KiB holds staging buffers + template ids
+
+size_t mfma2_bank_budget() { return V2_BANK_BUDGET; }
+
+template <int KSTEPS, int RPG, int MT>
+__global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
+    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t mtx, uint32_t n_rows, uint32_t n_pages,
+    const v4i *__restrict__ qbank, uint32_t n_tiles16, uint32_t n_chunk, const int32_t *__restrict__ negL, uint32_t Lpitch,
+    uint32_t Lrows, const uint32_t *__restrict__ tglobal, uint32_t n_total, uint64_t *__restrict__ cand,
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    v4i *bank = reinterpret_cast<v4i *>(smem);
+    const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + (size_t)bank_vec * 16 + (size_t)V2_WAVES * WBUF * 8);
+    for (uint32_t i = threadIdx.x; i < bank_vec; i += 512) bank[i] = qbank[i];
+    for (uint32_t i = threadIdx.x; i < n_tiles16 * 16; i += 512) tg_lds[i] = i < n_chunk ? tglobal[i] : 0xffffffffu;
+    __syncthreads();  // the only barrier
+
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: all tile coordinates stay in SGPRs
+    uint64_t *wbuf = reinterpret_cast<uint64_t *>(smem + (size_t)bank_vec * 16) + w * WBUF;
+    uint32_t wcount = 0;  // wave-uniform number of staged candidates
+
+    const uint32_t mt_per_page = mtx * n_rows;
+    const uint32_t total_mt = mt_per_page * n_pages;
+    const uint32_t n_items = (total_mt + MT - 1) / MT;
+    const uint32_t n_waves = gridDim.x * V2_WAVES;
+
+    v4i afrag[MT][KSTEPS];
+    for (uint32_t item = blockIdx.x * V2_WAVES + w; item < n_items; item += n_waves) {
+        // (page, row, column) of the item's first M-tile; the others follow by increment-with-carry
+        uint32_t m0 = item * MT;
+        uint32_t page = m0 / mt_per_page, rem = m0 % mt_per_page, row = rem / mtx, col = rem % mtx;
+        uint32_t px[MT], py[MT], pp[MT];
+        bool pv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            pv[mt] = m0 + mt < total_mt;
+            px[mt] = 16 * col;
+            py[mt] = 1 + row;  // y = 0 is never searched (src/ncc.cpp:302)
+            pp[mt] = pv[mt] ? page : n_pages - 1;
+            if (++col == mtx) {
+                col = 0;
+                if (++row == n_rows) {
+                    row = 0;
+                    ++page;
+                }
+            }
+        }
+
+        // C-in: lane (r, g) owns output rows 4g..4g+3 (windows px+4g+i) of every M-tile
+        v4i nl[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)  // unconditional loads (addresses are clamped): no branch, no wait between them
+            nl[mt] = *reinterpret_cast<const v4i *>(negL + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + 4 * g);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {  // M-tiles past the end of the enumeration: arithmetic select, never a branch
+            const int keep = pv[mt] ? -1 : 0;
+            nl[mt] = (nl[mt] & keep) | (v4i{-REJECT, -REJECT, -REJECT, -REJECT} & ~keep);
+        }
+
+        // A fragments: lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r.
+        // Byte-unaligned 16-byte (8-byte) global loads land directly in the MFMA operand registers.
+        if (!(dbg & 2) || item == blockIdx.x * V2_WAVES + w)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + ((dbg & 4) ? 0 : r);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                const int q = 4 * ks + g;
+                v4i a;
+                if (RPG == 1) {
+                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)q * pitch);
+                } else {
+                    const uint8_t *p0 = base + (size_t)(2 * q) * pitch;
+                    const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
+                    a = v4i{lo[0], lo[1], hi[0], hi[1]};
+                }
+                // u8 -> i8 (a - 128): the quantised templates sum to zero, so the bias cancels exactly
+                afrag[mt][ks] = a ^ (int)0x80808080;
+            }
+        }
+        // B fragments of N-tile nt are in registers before the tile starts; each one is re-loaded for
+        // N-tile nt+1 right after its last MFMA has issued, so the LDS latency hides behind the other K-steps.
+        v4i bf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = bank[ks * 64 + lane];
+        for (uint32_t nt = 0; nt < n_tiles16; nt++) {
+            v4i acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = nl[mt];
+            const uint32_t nxt = nt + 1 < n_tiles16 ? nt + 1 : nt;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[mt][ks], bf[ks], acc[mt], 0, 0, 0);
+                bf[ks] = bank[(nxt * KSTEPS + ks) * 64 + lane];
+            }
+            int mm[MT];  // per-M-tile maximum of the lane's four outputs
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) mm[mt] = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
+            int m = mm[0];
+#pragma unroll
+            for (int mt = 1; mt < MT; mt++) m = max(m, mm[mt]);
+            if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    if (__builtin_amdgcn_ballot_w64(mm[mt] > 0) == 0) continue;  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool f = acc[mt][i] > 0;
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(f);
+                        if (mask) {  // wave-uniform
+                            // dead / padding templates (tglobal = ~0) never emit; they only get here for thr <= 0
+                            const uint32_t tg = f ? tg_lds[nt * 16 + r] : 0xffffffffu;
+                            const bool ok = tg != 0xffffffffu;
+                            const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+                            const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
+                            if (cnt) {
+                                if (wcount + cnt > WBUF) {
+                                    flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                                    wcount = 0;
+                                }
+                                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
+                                // keep the key arithmetic inside this rare block (opaque inputs stop the compiler
+                                // from hoisting 8 M-tiles' worth of 64-bit keys out of the N-tile loop and spilling them)
+                                uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
+                                asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));
+                                if (ok)
+                                    wbuf[wcount + pos] = ((uint64_t)(pg * n_total + tg) << 32) | ((uint64_t)yy << 16) |
+                                                         (uint64_t)(xx + 4 * g + i);
+                                wcount += cnt;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+}
+
+template <int KSTEPS, int RPG, int MT>
+static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
+    const SizeClass &sc = *L.sc;
+    const uint32_t mtx = (uint32_t)((c->r_w - sc.n_w + 1 + 15) / 16);  // windows x in [0, r_w - n_w]
+    const uint32_t n_rows = (uint32_t)(c->r_h - sc.n_h);               // y in [1, r_h - n_h]
+    const uint32_t n_tiles16 = (L.chunk_n + 15) / 16;
+    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)V2_WAVES * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
+    const uint64_t total_mt = (uint64_t)mtx * n_rows * c->n_pages;
+    const uint64_t n_items = (total_mt + MT - 1) / MT;
+    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + V2_WAVES - 1) / V2_WAVES);
+    auto kern = scan_mfma2_kernel<KSTEPS, RPG, MT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + sc.q_offset + (size_t)(L.chunk_first / 16) * KSTEPS * 1024);
+    const uint64_t issued = n_items * MT * 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
+    const uint64_t alg = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * L.chunk_n * c->n_pages;
+    uint32_t dbg = 0;  // FOCR_MFMA_DBG: timing experiments only (bit0: skip candidate emission, bit1: reuse first A fragments)
+    if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
+    char name[64];
+    snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d>", KSTEPS, RPG, MT);
+    c->launch_begin(name, L.chunk_n, alg, issued);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, mtx,
+                       n_rows, (uint32_t)c->n_pages, qb, n_tiles16, L.chunk_n, L.negL, L.Lpitch, L.Lrows,
+                       c->d_tglobal + sc.first + L.chunk_first, (uint32_t)c->n_templates, c->d_cand,
+                       (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity, dbg);
+    c->launch_end();
+    c->counters[3] += issued;
+}
+
+int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
+    const uint32_t ks = L.sc->k_groups / 4, rpg = L.sc->rows_per_group;
+    if ((uint64_t)((c->r_w - L.sc->n_w + 16) / 16) * (c->r_h - L.sc->n_h) * c->n_pages >= 0xffffffffull / 2)
+        return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
+#define CASE(K, R, M)                  \
+    case (K) * 10 + (R):               \
+        launch_v2<K, R, M>(c, L, n_cus); \
+        break;
+    switch (ks * 10 + rpg) {
+        CASE(1, 1, 8) CASE(2, 1, 8) CASE(3, 1, 8) CASE(4, 1, 8) CASE(5, 1, 4) CASE(6, 1, 4) CASE(7, 1, 4) CASE(8, 1, 4)
+        CASE(1, 2, 8) CASE(2, 2, 8) CASE(3, 2, 8) CASE(4, 2, 8)
+        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+    }
+#undef CASE
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+}  // namespace focr

@@ -1,0 +1,19 @@
+"""Kernel-level timing of the scan at configs[1] (tools; not part of the product)."""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from font_ocr_amd import Bank, synth_pages
+from font_ocr_amd.searcher import Scanner, SCAN_MFMA
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bank = Bank.load(os.path.join(ROOT, "tests/golden/bank_dejavu13_ascii95_x2.bin"))
+P = int(os.environ.get("KB_PAGES", "128"))
+pages = synth_pages(bank, P, 608, 720)
+sc = Scanner(0); sc.set_bank(bank); sc.set_pages(pages)
+for _ in range(2): sc.scan(0.8, 1024, SCAN_MFMA)
+acc = {}
+N = 5
+for _ in range(N):
+    sc.scan(0.8, 1024, SCAN_MFMA)
+    for li in sc.launches(): acc[li["name"]] = acc.get(li["name"], 0) + li["ms"] / N
+t = sc.timings(); c = sc.counters()
+print(os.environ.get("FOCR_MFMA_DBG", "0"), {k: round(v, 3) for k, v in acc.items()}, {k: round(v, 3) for k, v in t.items()}, c["candidates"], c["raw_hits"])
