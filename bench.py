@@ -76,21 +76,25 @@ def main():
     sc.upload_pages_device(d_pages.data_ptr(), P, 0, invert=True)
     sc.sync()
 
+    class _DevBytes:  # zero-copy view of the library's device buffer for torch (no host round trip)
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
     def gather_lines():
-        """RCCL gather of the post-processed characters (variable length) to rank 0."""
-        lines = sc.lines_flat()
-        mine = torch.from_numpy(lines.view(np.uint8).reshape(-1)).to(dev)
-        n = torch.tensor([mine.numel()], device=dev, dtype=torch.int64)
+        """RCCL gather of the post-processed characters (variable length, device resident) to rank 0."""
+        ptr, cnt = sc.device_chars()
+        nbytes = cnt * HIT_DTYPE.itemsize
+        mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev) if nbytes else torch.zeros(0, dtype=torch.uint8, device=dev)
+        n = torch.tensor([nbytes], device=dev, dtype=torch.int64)
         sizes = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(sizes, n)
-        mx = int(max(int(s.item()) for s in sizes))
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(max(sizes), 1)
         buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        buf[: mine.numel()] = mine
+        buf[:nbytes] = mine
         out = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, out, dst=0)
-        if rank == 0:
-            return sum(int(s.item()) for s in sizes) // HIT_DTYPE.itemsize
-        return 0
+        return sum(sizes) // HIT_DTYPE.itemsize if rank == 0 else 0
 
     def step():
         sc.scan(args.threshold, 1024, mode)

@@ -96,6 +96,7 @@ HIP_SYMBOLS = {
     "focr_total_chars": (C.c_size_t, [C.c_void_p]),
     "focr_total_lines": (C.c_size_t, [C.c_void_p]),
     "focr_get_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "focr_lines_device_chars": (C.c_void_p, [C.c_void_p]),
     "focr_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_last_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_sync": (C.c_int, [C.c_void_p]),

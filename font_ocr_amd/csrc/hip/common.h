@@ -99,7 +99,15 @@ struct focr_ctx {
     size_t matches_alloc = 0;
     size_t n_matches = 0;
 
-    // process_hits results
+    // process_hits results (device-resident; copied to the host on focr_get_lines)
+    struct DevBuf {  // grow-only device scratch
+        void *p = nullptr;
+        size_t bytes = 0;
+        void *ensure(focr_ctx *c, size_t want);
+        void release();
+    };
+    DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
+    bool lines_on_host = false;
     bool processed = false;
     size_t n_chars = 0, n_lines = 0;
     std::vector<uint64_t> h_page_line_off, h_line_char_off;

@@ -79,6 +79,9 @@ static void free_results(focr_ctx *c) {
     free_dev(c->d_seg_offset);
     free_dev(c->d_matches);
     free_dev(c->d_match_keys);
+    for (auto *b : {&c->post_keep, &c->post_choice, &c->post_owner, &c->post_packed, &c->post_scanned, &c->post_page_off,
+                    &c->post_line_off, &c->post_chars})
+        b->release();
     c->hit_capacity = c->cand_capacity = c->L_bytes = c->sort_tmp_bytes = c->seg_alloc = c->matches_alloc = 0;
     c->scanned = c->processed = false;
 }
@@ -86,6 +89,27 @@ static void free_results(focr_ctx *c) {
 }  // namespace focr
 
 using namespace focr;
+
+void *focr_ctx::DevBuf::ensure(focr_ctx *c, size_t want) {
+    if (want <= bytes && p) return p;
+    (void)hipStreamSynchronize(c->stream);
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t grow = want + want / 4 + 256;
+    if (hipMalloc(&p, grow) != hipSuccess) {
+        p = nullptr;
+        return nullptr;
+    }
+    bytes = grow;
+    return p;
+}
+
+void focr_ctx::DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
 
 void focr_ctx::launch_begin(const char *name, uint32_t n_t, uint64_t alg, uint64_t issued) {
     focr_launch_info_t li{};

@@ -36,70 +36,107 @@ __global__ void copy_sims(const focr_match_t *__restrict__ m, size_t n, float *_
     if (i < n) sims[i] = m[i].similarity;
 }
 
-// One thread per line start walks its line (sorted by x, then t) and records, for the k-th group,
-// the index of the winning element at choice[line_start + k].  packed[i] = (is kept line start) << 32 | n_groups.
-__global__ void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n, uint32_t r_h,
-                           int32_t overlap, const uint8_t *__restrict__ keep, uint32_t *__restrict__ choice,
-                           uint64_t *__restrict__ packed) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t line = keys[i] >> 32;  // (page, y)
-    bool start = (i == 0) || ((keys[i - 1] >> 32) != line);
-    if (!start || !keep[(size_t)(line >> 16) * r_h + (uint32_t)(line & 0xffff)]) {
-        packed[i] = 0;
-        return;
+// One wave per (page, row): finds the row's extent in the sorted list by binary search, then walks it 64
+// elements at a time.  Groups are anchored on their first element (partition_by keeps `last` until a group
+// closes, src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave
+// operations: ballot for the group's extent inside the chunk, a 64-bit max-reduction for the winner
+// (key = total_cmp order of the similarity, then the element index, so the LAST maximum wins, :761-764).
+// Outputs: choice[b + k] = winning element of the k-th group, owner[b + k] = b, packed[b] = 1<<32 | groups.
+__global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n,
+                                                  uint32_t r_h, uint32_t n_rows_total, int32_t overlap,
+                                                  const uint8_t *__restrict__ keep, uint32_t *__restrict__ choice,
+                                                  uint32_t *__restrict__ owner, uint64_t *__restrict__ packed) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_rows_total) return;
+    if (!keep[wave]) return;  // keep is [page][y] with pitch r_h == wave index
+    const uint64_t line = ((uint64_t)(wave / r_h) << 16) | (uint64_t)(wave % r_h);  // (page, y)
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {  // first element of the line
+        uint64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> 32) < line) lo = mid + 1;
+        else hi = mid;
     }
+    const uint64_t b = lo;
+    hi = n;
+    while (lo < hi) {  // one past its last element
+        uint64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> 32) <= line) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint64_t e = lo;
+    if (b == e) return;
+
     uint32_t groups = 0;
-    size_t g = i;
-    while (g < n && (keys[g] >> 32) == line) {
-        const int32_t x_first = (int32_t)((keys[g] >> 16) & 0xffff);
-        size_t best = g;
-        int32_t best_key = total_key(sims[g]);
-        size_t e = g + 1;
-        while (e < n && (keys[e] >> 32) == line) {
-            int32_t x = (int32_t)((keys[e] >> 16) & 0xffff);
-            int32_t d = x_first - x;
-            if ((d < 0 ? -d : d) > overlap) break;
-            int32_t k = total_key(sims[e]);
-            if (k >= best_key) {  // max_by keeps the last maximum
-                best_key = k;
-                best = e;
+    bool open = false;          // a group is open (carried across chunks)
+    int32_t anchor = 0;         // x of the open group's first element
+    uint64_t best = 0;          // (total_key ^ sign fix) << 32 | element index, of the open group
+    for (uint64_t base = b; base < e; base += 64) {
+        const uint64_t i = base + lane;
+        const bool valid = i < e;
+        const int32_t x = valid ? (int32_t)((keys[i] >> 16) & 0xffff) : 0x7fffffff;
+        const uint32_t ord = valid ? ((uint32_t)total_key(sims[i]) ^ 0x80000000u) : 0u;  // unsigned order of total_cmp
+        const uint64_t mine = ((uint64_t)ord << 32) | (uint32_t)(i - b);
+        const uint32_t n_valid = (uint32_t)(e - base < 64 ? e - base : 64);
+        uint32_t pos = 0;  // wave-uniform cursor inside the chunk
+        while (pos < n_valid) {
+            if (!open) {
+                anchor = __shfl(x, (int)pos);
+                best = 0;
+                open = true;
             }
-            e++;
+            // members of the open group inside this chunk: lanes [pos, stop)
+            const bool in = lane >= pos && valid && (x - anchor <= overlap) && (anchor - x <= overlap);
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+            const uint64_t from = ~0ull << pos;
+            const uint64_t brk = ~inmask & from;  // first lane at/after pos that is not a member
+            const uint32_t stop = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
+            uint64_t v = (lane >= pos && lane < stop) ? mine : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint32_t vlo = __shfl_xor((uint32_t)v, o), vhi = __shfl_xor((uint32_t)(v >> 32), o);
+                const uint64_t other = ((uint64_t)vhi << 32) | vlo;
+                v = other > v ? other : v;
+            }
+            if (v > best) best = v;
+            if (stop < n_valid || base + 64 >= e) {  // the group closes inside this chunk (or the line ends)
+                if (lane == 0) {
+                    choice[b + groups] = (uint32_t)(b + (uint32_t)best);
+                    owner[b + groups] = (uint32_t)b;
+                }
+                groups++;
+                open = false;
+            }
+            pos = stop;
         }
-        choice[i + groups] = (uint32_t)best;
-        groups++;
-        g = e;
     }
-    packed[i] = ((uint64_t)1 << 32) | groups;
+    if (lane == 0) packed[b] = ((uint64_t)1 << 32) | groups;
 }
 
+// one thread per output character
 __global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n,
-                           const uint32_t *__restrict__ choice, const uint64_t *__restrict__ packed,
+                           const uint32_t *__restrict__ choice, const uint32_t *__restrict__ owner,
                            const uint64_t *__restrict__ scanned, const uint32_t *__restrict__ t_w,
                            const uint32_t *__restrict__ t_h, const uint32_t *__restrict__ t_letter,
                            uint64_t *__restrict__ line_char_off, focr_hit_t *__restrict__ chars) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t p = packed[i];
-    if (!(p >> 32)) return;
-    uint32_t groups = (uint32_t)p;
-    uint64_t line_idx = scanned[i] >> 32, off = scanned[i] & 0xffffffffu;
-    line_char_off[line_idx] = off;
-    for (uint32_t k = 0; k < groups; k++) {
-        uint32_t e = choice[i + k];
-        uint64_t key = keys[e];
-        uint32_t t = (uint32_t)(key & 0xffff);
-        focr_hit_t h;
-        h.x = (uint16_t)((key >> 16) & 0xffff);
-        h.y = (uint16_t)((key >> 32) & 0xffff);
-        h.w = (uint16_t)t_w[t];
-        h.h = (uint16_t)t_h[t];
-        h.similarity = sims[e];
-        h.letter = t_letter[t];
-        h.template_index = t;
-        chars[off + k] = h;
-    }
+    const uint32_t ls = owner[i];
+    if (ls == 0xffffffffu) return;
+    const uint64_t sc = scanned[ls];
+    const uint64_t off = (sc & 0xffffffffu) + (i - ls);
+    if (i == ls) line_char_off[sc >> 32] = sc & 0xffffffffu;
+    const uint32_t e = choice[i];
+    const uint64_t key = keys[e];
+    const uint32_t t = (uint32_t)(key & 0xffff);
+    focr_hit_t h;
+    h.x = (uint16_t)((key >> 16) & 0xffff);
+    h.y = (uint16_t)((key >> 32) & 0xffff);
+    h.w = (uint16_t)t_w[t];
+    h.h = (uint16_t)t_h[t];
+    h.similarity = sims[e];
+    h.letter = t_letter[t];
+    h.template_index = t;
+    chars[off] = h;
 }
 
 // page_line_off[p] = number of kept lines on pages < p
@@ -127,85 +164,80 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_process_hits: no scan results");
     FOCR_HIP(c, hipSetDevice(c->device));
     c->processed = false;
+    c->lines_on_host = false;
     const size_t n = c->n_matches, n_pages = c->n_pages;
-    c->h_page_line_off.assign(n_pages + 1, 0);
-    c->h_line_char_off.assign(1, 0);
-    c->h_chars.clear();
     c->n_chars = c->n_lines = 0;
     if (n == 0) {  // the reference panics on an empty hit list (src/ncc.rs:1040); we return zero lines
         c->processed = true;
         c->ms[4] = 0.f;
         return FOCR_OK;
     }
+    if (n >= 0xffffffffull) return fail(c, FOCR_ERR_OVERFLOW, "focr_process_hits: more than 2^32 matches in one batch");
     FOCR_HIP(c, hipEventRecord(c->ev[5], c->stream));
-    uint8_t *keep = nullptr;
-    uint32_t *choice = nullptr;
-    uint64_t *packed = nullptr, *scanned = nullptr, *d_line_off = nullptr, *d_page_off = nullptr;
-    focr_hit_t *d_chars = nullptr;
-    auto cleanup = [&]() {
-        for (void *p : {(void *)keep, (void *)choice, (void *)packed, (void *)scanned, (void *)d_line_off, (void *)d_page_off,
-                        (void *)d_chars})
-            if (p) (void)hipFree(p);
-    };
-#define PH(expr)                                                                              \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            cleanup();                                                                        \
-            return fail(c, FOCR_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-        }                                                                                     \
-    } while (0)
-    PH(hipMalloc(&keep, n_pages * c->r_h));
-    PH(hipMemsetAsync(keep, 0, n_pages * c->r_h, c->stream));
-    PH(hipMalloc(&choice, n * 4));
-    PH(hipMalloc(&packed, n * 8));
-    PH(hipMalloc(&scanned, n * 8));
+    // grow-only device scratch (no allocation in the steady state)
+    const size_t n_rows_total = n_pages * c->r_h;
+    uint8_t *keep = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
+    uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, n * 4);
+    uint32_t *owner = (uint32_t *)c->post_owner.ensure(c, n * 4);
+    uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, n * 8);
+    uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, n * 8);
+    uint64_t *d_page_off = (uint64_t *)c->post_page_off.ensure(c, (n_pages + 1) * 8);
+    if (!keep || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    FOCR_HIP(c, hipMemsetAsync(keep, 0, n_rows_total, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(owner, 0xff, n * 4, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(packed, 0, n * 8, c->stream));
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_matches, c->d_match_keys, n,
                        anchor_threshold, (uint32_t)c->r_h, keep);
     // sort (key = page|y|x|t, value = similarity); the hit buffers of the scan are reused as scratch
     hipLaunchKernelGGL(copy_sims, dim3(nb), dim3(256), 0, c->stream, c->d_matches, n, c->d_hit_sims);
-    PH(hipMemcpyAsync(c->d_hit_keys, c->d_match_keys, n * 8, hipMemcpyDeviceToDevice, c->stream));
-    int rc = sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims, c->d_hit_sims_alt, n, 64);
-    if (rc) {
-        cleanup();
-        return rc;
-    }
-    hipLaunchKernelGGL(walk_lines, dim3(nb), dim3(256), 0, c->stream, c->d_hit_keys, c->d_hit_sims, n, (uint32_t)c->r_h,
-                       overlap, keep, choice, packed);
-    rc = exclusive_scan_u64(c, packed, scanned, n);
-    if (rc) {
-        cleanup();
-        return rc;
-    }
+    FOCR_HIP(c, hipMemcpyAsync(c->d_hit_keys, c->d_match_keys, n * 8, hipMemcpyDeviceToDevice, c->stream));
+    unsigned page_bits = 1;
+    while (((size_t)1 << page_bits) < n_pages) page_bits++;
+    int rc = sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims, c->d_hit_sims_alt, n, 48 + page_bits);
+    if (rc) return rc;
+    hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hit_keys,
+                       c->d_hit_sims, n, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep, choice, owner, packed);
+    if ((rc = exclusive_scan_u64(c, packed, scanned, n))) return rc;
     uint64_t last_scan = 0, last_packed = 0;
-    PH(hipMemcpyAsync(&last_scan, scanned + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
-    PH(hipMemcpyAsync(&last_packed, packed + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
-    PH(hipStreamSynchronize(c->stream));
+    FOCR_HIP(c, hipMemcpyAsync(&last_scan, scanned + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    FOCR_HIP(c, hipMemcpyAsync(&last_packed, packed + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
     const uint64_t tot = last_scan + last_packed;
     c->n_lines = (size_t)(tot >> 32);
     c->n_chars = (size_t)(tot & 0xffffffffu);
-    PH(hipMalloc(&d_line_off, (c->n_lines + 1) * 8));
-    PH(hipMalloc(&d_page_off, (n_pages + 1) * 8));
-    PH(hipMalloc(&d_chars, (c->n_chars ? c->n_chars : 1) * sizeof(focr_hit_t)));
-    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hit_keys, c->d_hit_sims, n, choice, packed,
-                       scanned, c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
+    uint64_t *d_line_off = (uint64_t *)c->post_line_off.ensure(c, (c->n_lines + 1) * 8);
+    focr_hit_t *d_chars = (focr_hit_t *)c->post_chars.ensure(c, (c->n_chars ? c->n_chars : 1) * sizeof(focr_hit_t));
+    if (!d_line_off || !d_chars) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hit_keys, c->d_hit_sims, n, choice, owner, scanned,
+                       c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
     hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_hit_keys, n,
                        scanned, (uint64_t)c->n_lines, (uint32_t)n_pages, d_page_off);
-    PH(hipGetLastError());
+    FOCR_HIP(c, hipGetLastError());
+    FOCR_HIP(c, hipEventRecord(c->ev[6], c->stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    FOCR_HIP(c, hipEventElapsedTime(&c->ms[4], c->ev[5], c->ev[6]));
+    c->processed = true;
+    return FOCR_OK;
+}
+
+// results stay in HBM until somebody asks for them
+static int fetch_lines(focr_ctx *c) {
+    if (c->lines_on_host) return FOCR_OK;
+    c->h_page_line_off.assign(c->n_pages + 1, 0);
     c->h_line_char_off.assign(c->n_lines + 1, 0);
     c->h_chars.resize(c->n_chars);
-    if (c->n_lines) PH(hipMemcpyAsync(c->h_line_char_off.data(), d_line_off, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->n_matches) {
+        FOCR_HIP(c, hipSetDevice(c->device));
+        if (c->n_lines)
+            FOCR_HIP(c, hipMemcpyAsync(c->h_line_char_off.data(), c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(c->h_page_line_off.data(), c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        if (c->n_chars)
+            FOCR_HIP(c, hipMemcpyAsync(c->h_chars.data(), c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->h_line_char_off[c->n_lines] = c->n_chars;
-    PH(hipMemcpyAsync(c->h_page_line_off.data(), d_page_off, (n_pages + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    if (c->n_chars)
-        PH(hipMemcpyAsync(c->h_chars.data(), d_chars, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->stream));
-    PH(hipEventRecord(c->ev[6], c->stream));
-    PH(hipStreamSynchronize(c->stream));
-    PH(hipEventElapsedTime(&c->ms[4], c->ev[5], c->ev[6]));
-#undef PH
-    cleanup();
-    c->processed = true;
+    c->lines_on_host = true;
     return FOCR_OK;
 }
 
@@ -215,10 +247,16 @@ size_t focr_total_lines(focr_ctx_t *c) { return (c && c->processed) ? c->n_lines
 int focr_get_lines(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *line_char_offsets, focr_hit_t *chars) {
     if (!c) return FOCR_ERR_INVALID;
     if (!c->processed) return fail(c, FOCR_ERR_STATE, "focr_get_lines: call focr_process_hits first");
+    int rc = fetch_lines(c);
+    if (rc) return rc;
     if (page_line_offsets) memcpy(page_line_offsets, c->h_page_line_off.data(), c->h_page_line_off.size() * 8);
     if (line_char_offsets) memcpy(line_char_offsets, c->h_line_char_off.data(), c->h_line_char_off.size() * 8);
     if (chars && c->n_chars) memcpy(chars, c->h_chars.data(), c->n_chars * sizeof(focr_hit_t));
     return FOCR_OK;
+}
+
+const focr_hit_t *focr_lines_device_chars(focr_ctx_t *c) {
+    return (c && c->processed && c->n_chars) ? (const focr_hit_t *)c->post_chars.p : nullptr;
 }
 
 }  // extern "C"

@@ -176,6 +176,11 @@ class Scanner:
         self._ck(self._lib.focr_get_lines(self._h, None, None, _ptr(chars)))
         return chars
 
+    def device_chars(self):
+        """(device pointer, count) of the post-processed characters still resident in HBM (HIT_DTYPE records)."""
+        ptr = self._lib.focr_lines_device_chars(self._h)
+        return (int(ptr) if ptr else 0), int(self._lib.focr_total_chars(self._h))
+
     def total_chars(self):
         return int(self._lib.focr_total_chars(self._h))
 

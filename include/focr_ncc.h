@@ -168,6 +168,10 @@ size_t focr_total_lines(focr_ctx_t *ctx);
  * line_char_offsets: [total_lines+1] index into chars; chars: [total_chars]. */
 int focr_get_lines(focr_ctx_t *ctx, uint64_t *page_line_offsets, uint64_t *line_char_offsets,
                    focr_hit_t *chars);
+/* Device pointer to the focr_total_chars() post-processed characters (page, line, x order) of the
+ * last focr_process_hits, valid until the next scan/process call; NULL if there are none.  For
+ * device-side consumers (e.g. the RCCL gather of match lists across GPUs). */
+const focr_hit_t *focr_lines_device_chars(focr_ctx_t *ctx);
 
 /* Device time (ms, HIP events on the context's stream) of the phases of the
  * last focr_scan / focr_process_hits: [0] window statistics, [1] scan kernel
