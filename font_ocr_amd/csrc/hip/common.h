@@ -23,7 +23,7 @@ struct SizeClass {
     uint32_t n_templates;  // templates in this class
     uint32_t first;        // index of the class's first entry in the class-ordered arrays
     // MFMA prefilter layout
-    uint32_t rows_per_group;  // 2 if n_w <= 8 else 1: image rows packed in one 16-byte k-group
+    uint32_t layout;          // K layout of the MFMA prefilter (LAYOUT_W8 / W12 / W16, mfma_common.h)
     uint32_t k_groups;        // 16-byte k-groups per window (multiple of 4)
     uint32_t n_tiles16;       // ceil(n_templates / 16)
     uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
@@ -67,6 +67,8 @@ struct focr_ctx {
     uint8_t *d_needles = nullptr;               // dense needles (class-ordered, for verify)
     std::vector<uint32_t> h_needle_off;         // class-ordered byte offsets into d_needles
     uint32_t *d_needle_off = nullptr;
+    uint8_t *d_needles16 = nullptr;             // class-ordered, n_h rows of 16 bytes each (verify operand)
+    uint32_t *d_needle16_row = nullptr;         // class-ordered first row index into d_needles16
     uint32_t *d_t_w = nullptr, *d_t_h = nullptr, *d_t_letter = nullptr;  // by global template index
 
     // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded

@@ -55,6 +55,8 @@ static void free_bank(focr_ctx *c) {
     c->mfma_e_max.clear();
     free_dev(c->d_needles);
     free_dev(c->d_needle_off);
+    free_dev(c->d_needles16);
+    free_dev(c->d_needle16_row);
     free_dev(c->d_t_w);
     free_dev(c->d_t_h);
     free_dev(c->d_t_letter);

@@ -19,6 +19,38 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
     if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
 }
 
+// K layouts.  One MFMA K-step consumes 64 bytes of a window = four 16-byte k-groups, one per lane group
+// g = lane>>4.  A k-group is built from whole dwords of image rows, so it lands in the operand registers
+// straight from (byte-unaligned) global loads with no byte shuffling:
+//   LAYOUT_W16 (n_w 13..16): group q = row q, columns 0..15.                 K-step ks, lane group g: q = 4ks+g
+//   LAYOUT_W8  (n_w <= 8)  : group q = rows 2q, 2q+1, columns 0..7 each.     q = 4ks+g
+//   LAYOUT_W12 (n_w 9..12) : rows are 12 bytes; a quad of rows (4m..4m+3) fills exactly three groups
+//        p=0: row 4m   cols 0..11 | row 4m+1 cols 0..3
+//        p=1: row 4m+1 cols 4..11 | row 4m+2 cols 0..7
+//        p=2: row 4m+2 cols 8..11 | row 4m+3 cols 0..11
+//     and the (K-step, lane group) of quad m, part p is ks = 3*(m/4) + p, g = m%4, so that every lane of a
+//     K-step issues the same load widths.  16 rows -> 3 K-steps (192 bytes) instead of 4.
+// Template bytes outside n_w x n_h are zero, so the extra image bytes the A side picks up do not matter.
+enum { LAYOUT_W16 = 1, LAYOUT_W8 = 2, LAYOUT_W12 = 3 };
+
+// (row j, column x) of a template -> (K-step, lane group, byte in the 16-byte group)
+__host__ __device__ inline void kgroup_of(uint32_t layout, uint32_t j, uint32_t x, uint32_t *ks, uint32_t *g, uint32_t *byte) {
+    if (layout == LAYOUT_W16) {
+        *ks = j / 4, *g = j % 4, *byte = x;
+    } else if (layout == LAYOUT_W8) {
+        const uint32_t q = j / 2;
+        *ks = q / 4, *g = q % 4, *byte = 8 * (j % 2) + x;
+    } else {
+        const uint32_t m = j / 4, rr = j % 4;
+        uint32_t p, b;
+        if (rr == 0) p = 0, b = x;                          // row 4m: all 12 columns in part 0
+        else if (rr == 1) { if (x < 4) p = 0, b = 12 + x; else p = 1, b = x - 4; }
+        else if (rr == 2) { if (x < 8) p = 1, b = 8 + x; else p = 2, b = x - 8; }
+        else p = 2, b = 4 + x;
+        *ks = 3 * (m / 4) + p, *g = m % 4, *byte = b;
+    }
+}
+
 struct MfmaLaunch {
     const SizeClass *sc;
     uint32_t chunk_first, chunk_n;  // templates of the class covered by this launch (multiple of 16 except the last)

@@ -19,12 +19,9 @@
 //  3. exact verify (verify_kernel): the reference formula, operation for operation (common.h),
 //     on every candidate -> unordered hit list -> order.hip.
 //
-// Layout: A operand = windows.  Lane (r = lane&15, g = lane>>4) of a K-step holds 16 bytes of
-// window x0+r: the 16-byte k-group q = 4*kstep + g, which is image row y+q, columns x..x+15
-// (rows_per_group = 1, n_w in 9..16) or rows y+2q, y+2q+1, columns x..x+7 each (rows_per_group =
-// 2, n_w <= 8).  B operand = the quantised bank, staged once per block in LDS in exactly the
-// per-lane order the MFMA wants (1 KiB contiguous per ds_read_b128 wave-instruction, no bank
-// conflicts).  Every A fragment is built once per (tile, class) and reused for all templates.
+// Layout: A operand = windows, B operand = the quantised bank staged once per block in LDS in exactly the
+// per-lane order the MFMA wants; the K layouts (how image rows map to 16-byte k-groups) are in mfma_common.h.
+// The kernel itself is in scan_mfma2.hip.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -35,23 +32,32 @@ namespace focr {
 
 int ensure_hit_capacity(focr_ctx *c, size_t want);
 
-constexpr int MWAVES = 8;                 // window rows (= waves) per block tile
-constexpr int MPITCH = 96;                // LDS image-tile pitch in bytes (24 dwords: conflict-free A reads)
-constexpr size_t BANK_LDS_BUDGET = 72 << 10;  // bytes of LDS per block for the bank chunk (2 blocks / CU)
 
 // ---------------------------------------------------------------------------------------------
 // 1. window statistics -> negL table
-constexpr int STX = 64, STY = 4, SLDW = 21;
+//
+// Separable sliding sums: a block stages a (64 + n_w) x (32 + n_h - 1) byte tile, computes the horizontal
+// n_w-sums H (and H2 of squares) of every tile row once (v_dot4 on masked dwords), then each thread slides a
+// vertical n_h-window down its column: S(y+1) = S(y) + H(y+n_h) - H(y).  ~40 instructions per window instead
+// of ~300 for the direct evaluation.  Everything up to the threshold is exact integer arithmetic:
+//   V = n*s2 - s*s  (= n * norm2, exact),  window is live  <=>  V > 0
+// which is exactly the reference's "norm > 0" (src/ncc.rs:309: (f64)s2 - (f64)(s*s)/(f64)n is > 0 iff V > 0,
+// = 0 iff V = 0, because V/n >= 1/n is far above the rounding error of the division).
+// negL = -(floor(kq * sqrt(V)) - 2) with kq = kappa/sqrt(n) rounded toward -inf in f32: conservative
+// (f32 sqrt/convert/multiply errors are < 1 for |L| < 4e6; the -2 absorbs them).
+constexpr int STX = 64, STY = 32, SLDW = 21, SMAXROWS = STY + 31;
 
-template <int NDW, int MAXH>
+template <int NDW>
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
-                                                    uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, double kappa,
+                                                    uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, float kq,
                                                     int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows) {
-    constexpr int LROWS = STY + MAXH - 1;
-    __shared__ uint32_t tile[LROWS][SLDW];
+    __shared__ uint32_t tile[SMAXROWS][SLDW];
+    __shared__ uint32_t H[SMAXROWS][STX];
+    __shared__ uint32_t H2[SMAXROWS][STX];
     const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
+    const uint32_t rows = STY + n_h - 1;
     const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
-    for (uint32_t i = threadIdx.x; i < LROWS * SLDW; i += 256) {
+    for (uint32_t i = threadIdx.x; i < rows * SLDW; i += 256) {
         uint32_t r = i / SLDW, cdw = i % SLDW;
         uint32_t gy = y0 + r, gx = x0 + cdw * 4;
         uint32_t v = 0;
@@ -59,156 +65,66 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
         tile[r][cdw] = v;
     }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const uint32_t x = x0 + lane, y = y0 + wy;
-    const uint32_t cb = lane >> 2, sh = lane & 3;
-    uint32_t s_p = 0, s2_p = 0;
+    {  // horizontal sums
+        const uint32_t lane = threadIdx.x & 63, cb = lane >> 2, sh = lane & 3;
+        for (uint32_t r = threadIdx.x >> 6; r < rows; r += 4) {
+            uint32_t h = 0, h2 = 0;
 #pragma unroll
-    for (int j = 0; j < MAXH; j++) {
-#pragma unroll
-        for (int k = 0; k < NDW; k++) {
-            uint32_t lo = tile[wy + j][cb + k], hi = tile[wy + j][cb + k + 1];
-            uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-            uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu
-                            : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
-            w = ((uint32_t)j < n_h) ? (w & keep) : 0u;
-            s_p = __builtin_amdgcn_udot4(w, 0x01010101u, s_p, false);
-            s2_p = __builtin_amdgcn_udot4(w, w, s2_p, false);
+            for (int k = 0; k < NDW; k++) {
+                uint32_t lo = tile[r][cb + k], hi = tile[r][cb + k + 1];
+                uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu
+                                : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
+                w &= keep;
+                h = __builtin_amdgcn_udot4(w, 0x01010101u, h, false);
+                h2 = __builtin_amdgcn_udot4(w, w, h2, false);
+            }
+            H[r][lane] = h;
+            H2[r][lane] = h2;
         }
     }
-    if (x >= Lpitch || y >= Lrows) return;
-    // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
-    const bool in_range = x >= 1 && y >= 1 && x + n_w <= r_w && y + n_h <= r_h;
-    // same expression as patch_rnorm's argument (src/ncc.rs:309): norm2 <= 0 or NaN => rnorm = inf/NaN => never emitted
-    const double norm2 = (double)s2_p - ((double)((uint64_t)s_p * (uint64_t)s_p)) / (double)(n_w * n_h);
-    int32_t out = -REJECT;
-    if (in_range && norm2 > 0.0) {
-        double Lf = __builtin_floor(kappa * __builtin_sqrt(norm2)) - 2.0;
-        Lf = __builtin_fmin(__builtin_fmax(Lf, -(double)(REJECT - 1)), (double)REJECT);
-        out = -(int32_t)Lf;
+    __syncthreads();
+    const uint32_t col = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const uint32_t x = x0 + col;
+    if (x >= Lpitch) return;
+    constexpr uint32_t PER = STY / 4;  // window rows per thread
+    const uint32_t r0 = strip * PER;
+    uint32_t s = 0, s2 = 0;
+    for (uint32_t j = 0; j < n_h; j++) {
+        s += H[r0 + j][col];
+        s2 += H2[r0 + j][col];
     }
-    negL[((size_t)page * Lrows + y) * Lpitch + x] = out;
-}
-
-// ---------------------------------------------------------------------------------------------
-// 2. MFMA prefilter
-template <int KSTEPS, int RPG, int MT>
-__global__ __launch_bounds__(512, 4) void scan_mfma_kernel(
-    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t tiles_x, uint32_t tiles_y,
-    uint32_t n_pages, const v4i *__restrict__ qbank, uint32_t n_tiles16, uint32_t n_chunk,
-    const int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows, const uint32_t *__restrict__ tglobal,
-    uint32_t n_total, uint64_t *__restrict__ cand, unsigned long long *__restrict__ cand_counter,
-    unsigned long long cand_cap) {
-    constexpr int TROWS = MWAVES + 4 * KSTEPS * RPG - 1;  // image rows a tile touches
-    constexpr int TWID = 16 * MT;                         // windows per wave
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    v4i *bank = reinterpret_cast<v4i *>(smem);
-    const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
-    uint8_t *tile = smem + (size_t)bank_vec * 16;
-
-    for (uint32_t i = threadIdx.x; i < bank_vec; i += 512) bank[i] = qbank[i];
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    uint64_t *wbuf = reinterpret_cast<uint64_t *>(tile + ((TROWS * MPITCH + 15) & ~15)) + w * WBUF;
-    uint32_t wcount = 0;  // wave-uniform number of staged candidates
-    const uint32_t total_tiles = n_pages * tiles_y * tiles_x;
-
-    for (uint32_t tid = blockIdx.x; tid < total_tiles; tid += gridDim.x) {
-        const uint32_t tx = tid % tiles_x, ty = (tid / tiles_x) % tiles_y, page = tid / (tiles_x * tiles_y);
-        const uint32_t x0 = tx * TWID, y0 = ty * MWAVES;
-        const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
-        __syncthreads();  // previous tile's fragments are built (and the bank is staged on the first pass)
-        for (uint32_t i = threadIdx.x; i < TROWS * (MPITCH / 4); i += 512) {
-            uint32_t rr = i / (MPITCH / 4), cdw = i % (MPITCH / 4);
-            uint32_t gy = y0 + rr, gx = x0 + cdw * 4;
-            uint32_t v = 0;
-            if (gy < rows_alloc && gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t *>(pg + (size_t)gy * pitch + gx);
-            // u8 -> i8: a - 128 (the templates sum to zero, so the bias cancels exactly)
-            reinterpret_cast<uint32_t *>(tile)[rr * (MPITCH / 4) + cdw] = v ^ 0x80808080u;
+    const uint32_t n = n_w * n_h;
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t y = y0 + r0 + k;
+        if (y < Lrows) {
+            // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
+            const bool in_range = x >= 1 && y >= 1 && x + n_w <= r_w && y + n_h <= r_h;
+            const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;  // exact; > 0 <=> the reference's rnorm is finite
+            int32_t out = -REJECT;
+            if (in_range && V != 0) {
+                float Lf = __builtin_floorf(kq * __builtin_sqrtf((float)V)) - 2.0f;
+                Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+                out = -(int32_t)Lf;
+            }
+            negL[((size_t)page * Lrows + y) * Lpitch + x] = out;
         }
-        __syncthreads();
-
-        // A fragments: 16 bytes per lane per (M-tile, K-step)
-        v4i afrag[MT][KSTEPS];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const uint32_t col = 16 * mt + r, cb = col & ~3u, sh = col & 3u;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
-                const int q = 4 * ks + g;
-                if (RPG == 1) {
-                    const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + (w + q) * MPITCH + cb);
-                    uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
-                    afrag[mt][ks] = v4i{(int)__builtin_amdgcn_alignbyte(d1, d0, sh), (int)__builtin_amdgcn_alignbyte(d2, d1, sh),
-                                        (int)__builtin_amdgcn_alignbyte(d3, d2, sh), (int)__builtin_amdgcn_alignbyte(d4, d3, sh)};
-                } else {
-                    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(tile + (w + 2 * q) * MPITCH + cb);
-                    const uint32_t *p1 = reinterpret_cast<const uint32_t *>(tile + (w + 2 * q + 1) * MPITCH + cb);
-                    uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
-                    afrag[mt][ks] = v4i{(int)__builtin_amdgcn_alignbyte(a1, a0, sh), (int)__builtin_amdgcn_alignbyte(a2, a1, sh),
-                                        (int)__builtin_amdgcn_alignbyte(b1, b0, sh), (int)__builtin_amdgcn_alignbyte(b2, b1, sh)};
-                }
-            }
-        }
-        // C-in: lane (r, g) owns output rows 4g..4g+3 (= windows x0+16mt+4g+i) of every M-tile
-        const uint32_t y = y0 + w;
-        v4i nl[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-            nl[mt] = *reinterpret_cast<const v4i *>(negL + ((size_t)page * Lrows + y) * Lpitch + x0 + 16 * mt + 4 * g);
-
-        for (uint32_t nt = 0; nt < n_tiles16; nt++) {
-            v4i acc[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = nl[mt];
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
-                const v4i b = bank[(nt * KSTEPS + ks) * 64 + lane];
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                    acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[mt][ks], b, acc[mt], 0, 0, 0);
-            }
-            int m = acc[0][0];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                m = max(m, max(acc[mt][0], acc[mt][1]));
-                m = max(m, max(acc[mt][2], acc[mt][3]));
-            }
-            if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform, rare
-                const uint32_t tl = nt * 16 + r;
-                const uint32_t tg = tl < n_chunk ? tglobal[tl] : 0xffffffffu;  // dead / padding templates never emit
-                const bool lane_ok = tg != 0xffffffffu;
-                const uint64_t key_hi = ((uint64_t)(page * n_total + tg) << 32) | ((uint64_t)y << 16);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const bool f = lane_ok && acc[mt][i] > 0;
-                        const uint64_t mask = __builtin_amdgcn_ballot_w64(f);
-                        if (mask) {  // wave-uniform
-                            const uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
-                            if (wcount + cnt > WBUF) {
-                                flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
-                                wcount = 0;
-                            }
-                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            if (f) wbuf[wcount + pos] = key_hi | (uint64_t)(x0 + 16 * mt + 4 * g + i);
-                            wcount += cnt;
-                        }
-                    }
-            }
+        if (k + 1 < PER) {  // slide down one row
+            s += H[r0 + k + n_h][col] - H[r0 + k][col];
+            s2 += H2[r0 + k + n_h][col] - H2[r0 + k][col];
         }
     }
-    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
 // 3. exact verify: the reference arithmetic on every candidate
+typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
+
 __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, unsigned long long n_cand,
                                                      const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                      uint32_t n_total, const uint32_t *__restrict__ order_of,
-                                                     const TemplateConst *__restrict__ tc, const uint8_t *__restrict__ needles,
-                                                     const uint32_t *__restrict__ needle_off, double thr_d,
+                                                     const TemplateConst *__restrict__ tc, const v4i *__restrict__ needles16,
+                                                     const uint32_t *__restrict__ needle16_row, double thr_d,
                                                      uint64_t *__restrict__ hit_keys, float *__restrict__ hit_sims,
                                                      unsigned long long *__restrict__ counter, unsigned long long capacity) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,16 +134,24 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
     const uint32_t x = (uint32_t)(key & 0xffff), y = (uint32_t)((key >> 16) & 0xffff);
     const uint32_t ci = order_of[t];
     const TemplateConst c = tc[ci];
-    const uint8_t *nd = needles + needle_off[ci];
-    const uint8_t *pg = pages + ((size_t)page * rows_alloc + y) * pitch + x;
+    const v4i *nd = needles16 + needle16_row[ci];  // n_h rows of 16 bytes, zero padded past n_w
+    const uint8_t *pg = pages + ((size_t)page * rows_alloc + y) * pitch + x;  // rows have >= 64 readable bytes past r_w
+    // byte mask of the window's own n_w columns (the padded template columns are zero, but s_p / s2_p need the mask)
+    v4i keep;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        keep[k] = c.n_w >= (uint32_t)(4 * k + 4) ? -1 : (c.n_w <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (c.n_w - 4 * k))) - 1u));
     uint32_t acc = 0, s_p = 0, s2_p = 0;
-    for (uint32_t j = 0; j < c.n_h; j++)
-        for (uint32_t k = 0; k < c.n_w; k++) {
-            uint32_t a = pg[(size_t)j * pitch + k], b = nd[j * c.n_w + k];
-            acc += a * b;    // src/ncc.cpp:316-321
-            s_p += a;        // patch_sum,  src/ncc.rs:307, 310
-            s2_p += a * a;   // window sum of squares, src/ncc.rs:308
+    for (uint32_t j = 0; j < c.n_h; j++) {
+        const v4i a = *reinterpret_cast<const v4i_u *>(pg + (size_t)j * pitch) & keep;
+        const v4i b = nd[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
+            s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
+            s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
         }
+    }
     const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
     const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
     if (ncc_emits(sim, thr_d)) {
@@ -248,9 +172,11 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     std::vector<uint32_t> tglobal(c->h_tconst.size(), 0xffffffffu), order_of(c->n_templates, 0);
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
-        sc.rows_per_group = sc.n_w <= 8 ? 2 : 1;
-        const uint32_t groups = (sc.n_h + sc.rows_per_group - 1) / sc.rows_per_group;
-        sc.k_groups = (groups + 3) / 4 * 4;
+        // K layout (see mfma_common.h): 8-, 12- or 16-byte image rows packed into 16-byte k-groups
+        sc.layout = sc.n_w <= 8 ? LAYOUT_W8 : (sc.n_w <= 12 ? LAYOUT_W12 : LAYOUT_W16);
+        if (sc.layout == LAYOUT_W8) sc.k_groups = ((sc.n_h + 1) / 2 + 3) / 4 * 4;   // 2 rows per group
+        else if (sc.layout == LAYOUT_W12) sc.k_groups = (sc.n_h + 15) / 16 * 12;    // 16 rows -> 12 groups (3 K-steps)
+        else sc.k_groups = (sc.n_h + 3) / 4 * 4;                                    // 1 row per group
         sc.n_tiles16 = (sc.n_templates + 15) / 16;
         sc.q_offset = (uint32_t)qbank.size();
         const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4;
@@ -310,15 +236,8 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
             const uint32_t nt = i / 16, nn = i % 16;
             for (uint32_t j = 0; j < sc.n_h; j++)
                 for (uint32_t x = 0; x < sc.n_w; x++) {
-                    uint32_t qg, byte;
-                    if (sc.rows_per_group == 1) {
-                        qg = j;
-                        byte = x;
-                    } else {
-                        qg = j / 2;
-                        byte = 8 * (j % 2) + x;
-                    }
-                    const uint32_t ks = qg / 4, g = qg % 4;
+                    uint32_t ks, g, byte;
+                    kgroup_of(sc.layout, j, x, &ks, &g, &byte);
                     qbank[sc.q_offset + ((size_t)(nt * ksteps + ks) * 64 + g * 16 + nn) * 16 + byte] = (int8_t)bq[j * sc.n_w + x];
                 }
         }
@@ -330,59 +249,35 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     FOCR_HIP(c, hipMemcpy(c->d_qbank, qbank.data(), qbank.size(), hipMemcpyHostToDevice));
     FOCR_HIP(c, hipMalloc((void **)&c->d_tglobal, tglobal.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_tglobal, tglobal.data(), tglobal.size() * 4, hipMemcpyHostToDevice));
+    // verify operand: every template as n_h rows of 16 bytes (zero padded), class-ordered
+    std::vector<uint8_t> n16;
+    std::vector<uint32_t> n16_row(c->h_tconst.size(), 0);
+    for (size_t ci = 0; ci < c->h_tconst.size(); ci++) {
+        const TemplateConst &tc = c->h_tconst[ci];
+        n16_row[ci] = (uint32_t)(n16.size() / 16);
+        const uint8_t *nd = dense + c->h_needle_off[ci];
+        for (uint32_t j = 0; j < tc.n_h; j++)
+            for (uint32_t x = 0; x < 16; x++) n16.push_back(x < tc.n_w ? nd[j * tc.n_w + x] : 0);
+    }
+    FOCR_HIP(c, hipMalloc((void **)&c->d_needles16, n16.size() ? n16.size() : 16));
+    FOCR_HIP(c, hipMemcpy(c->d_needles16, n16.data(), n16.size(), hipMemcpyHostToDevice));
+    FOCR_HIP(c, hipMalloc((void **)&c->d_needle16_row, n16_row.size() * 4));
+    FOCR_HIP(c, hipMemcpy(c->d_needle16_row, n16_row.data(), n16_row.size() * 4, hipMemcpyHostToDevice));
     FOCR_HIP(c, hipMalloc((void **)&c->d_order_of, order_of.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_order_of, order_of.data(), order_of.size() * 4, hipMemcpyHostToDevice));
     return FOCR_OK;
 }
 
-template <int NDW, int MAXH>
+template <int NDW>
 static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t *negL, uint32_t Lpitch, uint32_t Lrows) {
     dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->n_pages);
-    hipLaunchKernelGGL((stats_kernel<NDW, MAXH>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
-                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kappa, negL, Lpitch, Lrows);
-}
-
-template <int KSTEPS, int RPG, int MT>
-static void launch_mfma(focr_ctx *c, const MfmaLaunch &L, unsigned n_blocks) {
-    const SizeClass &sc = *L.sc;
-    const uint32_t twid = 16 * MT;
-    const uint32_t tiles_x = (uint32_t)((c->r_w - sc.n_w + 1 + twid - 1) / twid);  // windows x in [0, r_w - n_w]
-    const uint32_t tiles_y = (uint32_t)((c->r_h - sc.n_h + 1 + MWAVES - 1) / MWAVES);
-    const uint32_t n_tiles16 = (L.chunk_n + 15) / 16;
-    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (((size_t)(MWAVES + 4 * KSTEPS * RPG - 1) * MPITCH + 15) & ~(size_t)15) +
-                       (size_t)MWAVES * WBUF * 8;
-    const uint64_t total_tiles = (uint64_t)tiles_x * tiles_y * c->n_pages;
-    unsigned grid = (unsigned)std::min<uint64_t>(n_blocks, total_tiles);
-    auto kern = scan_mfma_kernel<KSTEPS, RPG, MT>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + sc.q_offset + (size_t)(L.chunk_first / 16) * KSTEPS * 1024);
-    const uint64_t issued = total_tiles * MWAVES * twid * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
-    const uint64_t alg = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * L.chunk_n * c->n_pages;
-    char name[64];
-    snprintf(name, sizeof name, "scan_mfma_kernel<%d,%d,%d>", KSTEPS, RPG, MT);
-    c->launch_begin(name, L.chunk_n, alg, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
-                       tiles_x, tiles_y, (uint32_t)c->n_pages, qb, n_tiles16, L.chunk_n, L.negL, L.Lpitch, L.Lrows,
-                       c->d_tglobal + sc.first + L.chunk_first, (uint32_t)c->n_templates, c->d_cand,
-                       (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
-    c->launch_end();
-    c->counters[3] += issued;
-}
-
-static int dispatch_mfma(focr_ctx *c, const MfmaLaunch &L, unsigned n_blocks) {
-    const uint32_t ks = L.sc->k_groups / 4, rpg = L.sc->rows_per_group;
-#define CASE(K, R, M)                 \
-    case (K) * 10 + (R):              \
-        launch_mfma<K, R, M>(c, L, n_blocks); \
-        break;
-    switch (ks * 10 + rpg) {
-        CASE(1, 1, 4) CASE(2, 1, 4) CASE(3, 1, 4) CASE(4, 1, 4) CASE(5, 1, 2) CASE(6, 1, 2) CASE(7, 1, 2) CASE(8, 1, 2)
-        CASE(1, 2, 4) CASE(2, 2, 4) CASE(3, 2, 4) CASE(4, 2, 4)
-        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
-    }
-#undef CASE
-    FOCR_HIP(c, hipGetLastError());
-    return FOCR_OK;
+    // kq = kappa / sqrt(n), rounded toward -inf so that the f32 product never overshoots the true threshold
+    const double kq_d = kappa / std::sqrt((double)(sc.n_w * sc.n_h));
+    float kq = (float)kq_d;
+    if ((double)kq > kq_d) kq = std::nextafterf(kq, -INFINITY);
+    kq = std::nextafterf(kq, -INFINITY);
+    hipLaunchKernelGGL((stats_kernel<NDW>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
+                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows);
 }
 
 int launch_scan_mfma(focr_ctx *c, float threshold) {
@@ -403,9 +298,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->n_pages * 131072));
     hipDeviceProp_t prop;
     FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
-    const unsigned n_blocks = 2u * (unsigned)prop.multiProcessorCount;
-    int variant = 2;  // FOCR_MFMA_VARIANT=1 selects the LDS-tiled, barrier-per-tile kernel (kept for A/B)
-    if (const char *e = getenv("FOCR_MFMA_VARIANT")) variant = atoi(e) == 1 ? 1 : 2;
 
     for (int attempt = 0; attempt < 4; attempt++) {
         if (c->cand_capacity < want_cand) {
@@ -427,15 +319,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
             const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
             int32_t *negL = c->d_L + k * L_per_class;
-            switch (sc.ndw * 100 + sc.maxh) {
-                case 116: launch_stats<1, 16>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 216: launch_stats<2, 16>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 316: launch_stats<3, 16>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 416: launch_stats<4, 16>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 132: launch_stats<1, 32>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 232: launch_stats<2, 32>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 332: launch_stats<3, 32>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 432: launch_stats<4, 32>(c, sc, kappa, negL, Lpitch, Lrows); break;
+            switch (sc.ndw) {
+                case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows); break;
+                case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows); break;
+                case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows); break;
+                case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows); break;
                 default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
             }
             FOCR_HIP(c, hipGetLastError());
@@ -446,11 +334,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const SizeClass &sc = c->classes[k];
             if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
             const uint32_t ksteps = sc.k_groups / 4;
-            const size_t budget = variant == 1 ? BANK_LDS_BUDGET : mfma2_bank_budget();
+            const size_t budget = mfma2_bank_budget();
             const uint32_t chunk_max = (uint32_t)(budget / (ksteps * 1024)) * 16;
             for (uint32_t first = 0; first < sc.n_templates; first += chunk_max) {
                 MfmaLaunch L{&sc, first, std::min(chunk_max, sc.n_templates - first), c->d_L + k * L_per_class, Lpitch, Lrows};
-                rc = variant == 1 ? dispatch_mfma(c, L, n_blocks) : dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount);
+                rc = dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount);
                 if (rc) return rc;
             }
         }
@@ -469,7 +357,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         if (n_cand) {
             hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand,
                                c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, (uint32_t)c->n_templates, c->d_order_of,
-                               c->d_tconst, c->d_needles, c->d_needle_off, thr_d, c->d_hit_keys, c->d_hit_sims,
+                               c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_keys, c->d_hit_sims,
                                (unsigned long long *)c->d_counter, (unsigned long long)c->hit_capacity);
             FOCR_HIP(c, hipGetLastError());
         }

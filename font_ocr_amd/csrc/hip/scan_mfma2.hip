@@ -1,7 +1,6 @@
 // scan_mfma2.hip — barrier-free i8 MFMA prefilter (default variant).
 //
-// Same arithmetic and B-operand layout as scan_mfma.hip (see its header for the maths); what
-// changes is who feeds the A operand.  Here every wave is an independent worker: it takes MT
+// The maths is in scan_mfma.hip's header, the K layouts in mfma_common.h.  Every wave is an independent worker: it takes MT
 // consecutive 16-window M-tiles of the (page, row, column) enumeration, reads its A fragments
 // straight from the page in HBM/L2 (two aligned loads + v_alignbyte per 16-byte k-group; the page
 // is read ~16x per class, all but the first time from L2), and streams the whole quantised bank
@@ -17,6 +16,9 @@ namespace focr {
 typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned views: gfx950 global loads take any alignment
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef v2i v2i_u __attribute__((aligned(1)));
+typedef int v3i __attribute__((ext_vector_type(3)));
+typedef v3i v3i_u __attribute__((aligned(1)));
+typedef int int_u __attribute__((aligned(1)));
 
 constexpr int V2_WAVES = 8;
 constexpr size_t V2_BANK_BUDGET = 136 << 10;  // one block per CU: the rest of the 160 KiB holds staging buffers + template ids
@@ -88,14 +90,27 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
             const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + ((dbg & 4) ? 0 : r);
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ks++) {
-                const int q = 4 * ks + g;
                 v4i a;
-                if (RPG == 1) {
-                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)q * pitch);
-                } else {
-                    const uint8_t *p0 = base + (size_t)(2 * q) * pitch;
+                if (RPG == LAYOUT_W16) {
+                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)(4 * ks + g) * pitch);
+                } else if (RPG == LAYOUT_W8) {
+                    const uint8_t *p0 = base + (size_t)(2 * (4 * ks + g)) * pitch;
                     const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
                     a = v4i{lo[0], lo[1], hi[0], hi[1]};
+                } else {  // LAYOUT_W12: row quad m = 4*(ks/3)+g, part p = ks%3 (compile-time)
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
+                    if (ks % 3 == 0) {
+                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
+                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
+                        a = v4i{t[0], t[1], t[2], u};
+                    } else if (ks % 3 == 1) {
+                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
+                        a = v4i{t[0], t[1], u[0], u[1]};
+                    } else {
+                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
+                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
+                        a = v4i{t, u[0], u[1], u[2]};
+                    }
                 }
                 // u8 -> i8 (a - 128): the quantised templates sum to zero, so the bias cancels exactly
                 afrag[mt][ks] = a ^ (int)0x80808080;
@@ -191,7 +206,7 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
 }
 
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
-    const uint32_t ks = L.sc->k_groups / 4, rpg = L.sc->rows_per_group;
+    const uint32_t ks = L.sc->k_groups / 4, rpg = L.sc->layout;
     if ((uint64_t)((c->r_w - L.sc->n_w + 16) / 16) * (c->r_h - L.sc->n_h) * c->n_pages >= 0xffffffffull / 2)
         return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
 #define CASE(K, R, M)                  \
@@ -201,6 +216,7 @@ int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     switch (ks * 10 + rpg) {
         CASE(1, 1, 8) CASE(2, 1, 8) CASE(3, 1, 8) CASE(4, 1, 8) CASE(5, 1, 4) CASE(6, 1, 4) CASE(7, 1, 4) CASE(8, 1, 4)
         CASE(1, 2, 8) CASE(2, 2, 8) CASE(3, 2, 8) CASE(4, 2, 8)
+        CASE(3, 3, 8) CASE(6, 3, 4)
         default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
     }
 #undef CASE
