@@ -27,7 +27,18 @@ struct SizeClass {
     uint32_t k_groups;        // 16-byte k-groups per window (multiple of 4)
     uint32_t n_tiles16;       // ceil(n_templates / 16)
     uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
+    uint32_t tg_offset;       // entry offset of the class's template ids in d_tglobal (16 per N-tile, ~0 = padding/dead)
     float kappa;              // prefilter slope: flag iff G > kappa * norm_p (see scan_mfma.hip)
+};
+
+// Classes whose A fragments are identical (same K layout, same number of K-steps) are scanned in one kernel
+// pass: their N-tiles are concatenated; only the C-in table (negL) changes from class to class.
+struct SuperClass {
+    uint32_t layout, ksteps;
+    std::vector<uint32_t> classes;     // indices into focr_ctx::classes
+    std::vector<uint32_t> tile_first;  // first N-tile of each class inside the super-class
+    uint32_t n_tiles;
+    size_t q_offset, tg_offset;
 };
 
 // Per-template constants, computed once on the host in IEEE double exactly as
@@ -56,6 +67,7 @@ struct focr_ctx {
     size_t n_templates = 0;
     std::vector<focr_template_t> h_templates;
     std::vector<focr::SizeClass> classes;
+    std::vector<focr::SuperClass> supers;
     std::vector<focr::TemplateConst> h_tconst;  // class-ordered
     focr::TemplateConst *d_tconst = nullptr;    // class-ordered
     uint32_t *d_direct_bank = nullptr;          // class-ordered, [maxh][ndw] dwords each

@@ -51,14 +51,32 @@ __host__ __device__ inline void kgroup_of(uint32_t layout, uint32_t j, uint32_t 
     }
 }
 
-struct MfmaLaunch {
-    const SizeClass *sc;
-    uint32_t chunk_first, chunk_n;  // templates of the class covered by this launch (multiple of 16 except the last)
-    const int32_t *negL;
-    uint32_t Lpitch, Lrows;
+// One kernel pass = one bank chunk (contiguous N-tiles of a super-class) made of up to MAX_SEGS segments,
+// each segment being the tiles of one size class (its own negL table).
+constexpr int MAX_SEGS = 8;
+struct MfmaSeg {
+    const int32_t *negL;  // class's C-in table [page][Lrows][Lpitch]
+    uint32_t tile_end;    // one past the segment's last N-tile, in chunk-local numbering (segments are contiguous)
+    uint32_t pad;
+};
+struct MfmaSegs {
+    MfmaSeg s[MAX_SEGS];
+    uint32_t n;
 };
 
-// scan_mfma2.hip: barrier-free variant (one wave = one independent work item stream)
+struct MfmaLaunch {
+    uint32_t layout, ksteps;
+    size_t q_offset;      // byte offset of the chunk's first N-tile in d_qbank
+    size_t tg_offset;     // entry offset of the chunk's template ids in d_tglobal
+    uint32_t n_tiles16;   // N-tiles in the chunk
+    uint32_t n_templates; // real templates in the chunk
+    uint32_t min_w, min_h;  // smallest template of the chunk: defines the window enumeration
+    MfmaSegs segs;
+    uint32_t Lpitch, Lrows;
+    uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)
+};
+
+// scan_mfma2.hip
 size_t mfma2_bank_budget();
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);
 

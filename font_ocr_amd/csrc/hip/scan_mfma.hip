@@ -168,17 +168,50 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
 
 // Quantise the bank (see the header comment).  `dense` holds the class-ordered dense needles.
 int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
-    std::vector<int8_t> qbank;
-    std::vector<uint32_t> tglobal(c->h_tconst.size(), 0xffffffffu), order_of(c->n_templates, 0);
+    // K layout per class (mfma_common.h).  Narrow classes ride the 12-byte-row layout whenever a 9..12-wide
+    // class exists, so that all of them share one set of A fragments (one "super-class", one kernel pass).
+    bool any_mid = false;
+    for (const SizeClass &sc : c->classes) any_mid |= (sc.n_w >= 9 && sc.n_w <= 12);
+    c->supers.clear();
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
-        // K layout (see mfma_common.h): 8-, 12- or 16-byte image rows packed into 16-byte k-groups
-        sc.layout = sc.n_w <= 8 ? LAYOUT_W8 : (sc.n_w <= 12 ? LAYOUT_W12 : LAYOUT_W16);
+        sc.layout = sc.n_w >= 13 ? LAYOUT_W16 : (any_mid ? LAYOUT_W12 : LAYOUT_W8);
         if (sc.layout == LAYOUT_W8) sc.k_groups = ((sc.n_h + 1) / 2 + 3) / 4 * 4;   // 2 rows per group
         else if (sc.layout == LAYOUT_W12) sc.k_groups = (sc.n_h + 15) / 16 * 12;    // 16 rows -> 12 groups (3 K-steps)
         else sc.k_groups = (sc.n_h + 3) / 4 * 4;                                    // 1 row per group
         sc.n_tiles16 = (sc.n_templates + 15) / 16;
-        sc.q_offset = (uint32_t)qbank.size();
+        size_t si = 0;
+        for (; si < c->supers.size(); si++)
+            if (c->supers[si].layout == sc.layout && c->supers[si].ksteps == sc.k_groups / 4) break;
+        if (si == c->supers.size()) {
+            SuperClass su{};
+            su.layout = sc.layout;
+            su.ksteps = sc.k_groups / 4;
+            c->supers.push_back(su);
+        }
+        SuperClass &su = c->supers[si];
+        su.classes.push_back((uint32_t)k);
+        su.tile_first.push_back(su.n_tiles);
+        su.n_tiles += sc.n_tiles16;
+    }
+    size_t q_bytes = 0, tg_entries = 0;
+    for (SuperClass &su : c->supers) {
+        su.q_offset = q_bytes;
+        su.tg_offset = tg_entries;
+        q_bytes += (size_t)su.n_tiles * su.ksteps * 1024;
+        tg_entries += (size_t)su.n_tiles * 16;
+        for (size_t i = 0; i < su.classes.size(); i++) {
+            SizeClass &sc = c->classes[su.classes[i]];
+            sc.q_offset = (uint32_t)(su.q_offset + (size_t)su.tile_first[i] * su.ksteps * 1024);
+            sc.tg_offset = (uint32_t)(su.tg_offset + (size_t)su.tile_first[i] * 16);
+        }
+    }
+    std::vector<int8_t> qbank(q_bytes, 0);
+    std::vector<uint32_t> tglobal(tg_entries, 0xffffffffu), order_of(c->n_templates, 0);
+    c->mfma_c_scale.clear();
+    c->mfma_e_max.clear();
+    for (size_t k = 0; k < c->classes.size(); k++) {
+        SizeClass &sc = c->classes[k];
         const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4;
         // bank-wide scale: 126 / max |b - mean| / norm_n over live templates
         double max_ratio = 0.0;
@@ -196,13 +229,11 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
             double n2 = s2 - s * s / n;
             if (!(n2 > 0.0) || !std::isfinite(tc.rnorm_n)) continue;  // constant needle: rnorm_n = inf, never emits
             norm_n[i] = std::sqrt(n2);
-            tglobal[sc.first + i] = tc.index;
+            tglobal[sc.tg_offset + i] = tc.index;
             for (uint32_t p = 0; p < n; p++) max_ratio = std::max(max_ratio, std::fabs(nd[p] - mean[i]) / norm_n[i]);
         }
         const double c_scale = max_ratio > 0 ? 126.0 / max_ratio : 1.0;
         double e_max = 0.0;
-        const size_t class_bytes = (size_t)sc.n_tiles16 * ksteps * 1024;
-        qbank.resize(sc.q_offset + class_bytes, 0);
         std::vector<double> rk(n);
         std::vector<int> bq(n);
         std::vector<uint32_t> idx(n);
@@ -329,17 +360,50 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             FOCR_HIP(c, hipGetLastError());
         }
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
-        // 2. MFMA prefilter, one launch per (class, bank chunk that fits the LDS budget)
-        for (size_t k = 0; k < c->classes.size(); k++) {
-            const SizeClass &sc = c->classes[k];
-            if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
-            const uint32_t ksteps = sc.k_groups / 4;
-            const size_t budget = mfma2_bank_budget();
-            const uint32_t chunk_max = (uint32_t)(budget / (ksteps * 1024)) * 16;
-            for (uint32_t first = 0; first < sc.n_templates; first += chunk_max) {
-                MfmaLaunch L{&sc, first, std::min(chunk_max, sc.n_templates - first), c->d_L + k * L_per_class, Lpitch, Lrows};
-                rc = dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount);
-                if (rc) return rc;
+        // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget)
+        for (const SuperClass &su : c->supers) {
+            const uint32_t chunk_tiles = (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
+            uint32_t t0 = 0;
+            while (t0 < su.n_tiles) {
+                MfmaLaunch L{};
+                L.layout = su.layout;
+                L.ksteps = su.ksteps;
+                L.Lpitch = Lpitch;
+                L.Lrows = Lrows;
+                L.min_w = L.min_h = 0xffffffffu;
+                const uint32_t t_limit = std::min(su.n_tiles, t0 + chunk_tiles);
+                uint32_t t1 = t0;
+                for (size_t i = 0; i < su.classes.size() && L.segs.n < (uint32_t)MAX_SEGS; i++) {
+                    const SizeClass &sc = c->classes[su.classes[i]];
+                    const uint32_t cb = su.tile_first[i], ce = cb + sc.n_tiles16;
+                    const uint32_t b = std::max(cb, t1), e = std::min(ce, t_limit);
+                    if (b >= e || b != t1) continue;  // segments must tile [t0, t1) contiguously
+                    if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) {  // no searchable window: skip the class's tiles
+                        if (L.segs.n == 0) {
+                            t0 = t1 = e;
+                            continue;
+                        }
+                        break;
+                    }
+                    MfmaSeg &sg = L.segs.s[L.segs.n++];
+                    sg.negL = c->d_L + su.classes[i] * L_per_class;
+                    sg.tile_end = e - t0;
+                    const uint32_t real = std::min(sc.n_templates, (e - cb) * 16) - (b - cb) * 16;
+                    L.n_templates += real;
+                    L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->n_pages;
+                    L.min_w = std::min(L.min_w, sc.n_w);
+                    L.min_h = std::min(L.min_h, sc.n_h);
+                    t1 = e;
+                }
+                if (L.segs.n == 0) {
+                    if (t1 == t0) break;
+                    continue;
+                }
+                L.n_tiles16 = t1 - t0;
+                L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
+                L.tg_offset = su.tg_offset + (size_t)t0 * 16;
+                if ((rc = dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount))) return rc;
+                t0 = t1;
             }
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));

@@ -20,23 +20,22 @@ typedef int v3i __attribute__((ext_vector_type(3)));
 typedef v3i v3i_u __attribute__((aligned(1)));
 typedef int int_u __attribute__((aligned(1)));
 
-constexpr int V2_WAVES = 8;
 constexpr size_t V2_BANK_BUDGET = 136 << 10;  // one block per CU: the rest of the 160 KiB holds staging buffers + template ids
 
 size_t mfma2_bank_budget() { return V2_BANK_BUDGET; }
 
-template <int KSTEPS, int RPG, int MT>
-__global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
+template <int KSTEPS, int RPG, int MT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t mtx, uint32_t n_rows, uint32_t n_pages,
-    const v4i *__restrict__ qbank, uint32_t n_tiles16, uint32_t n_chunk, const int32_t *__restrict__ negL, uint32_t Lpitch,
-    uint32_t Lrows, const uint32_t *__restrict__ tglobal, uint32_t n_total, uint64_t *__restrict__ cand,
+    const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
+    const uint32_t *__restrict__ tglobal, uint32_t n_total, uint64_t *__restrict__ cand,
     unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
-    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + (size_t)bank_vec * 16 + (size_t)V2_WAVES * WBUF * 8);
-    for (uint32_t i = threadIdx.x; i < bank_vec; i += 512) bank[i] = qbank[i];
-    for (uint32_t i = threadIdx.x; i < n_tiles16 * 16; i += 512) tg_lds[i] = i < n_chunk ? tglobal[i] : 0xffffffffu;
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + (size_t)bank_vec * 16 + (size_t)NW * WBUF * 8);
+    for (uint32_t i = threadIdx.x; i < bank_vec; i += NW * 64) bank[i] = qbank[i];
+    for (uint32_t i = threadIdx.x; i < n_tiles16 * 16; i += NW * 64) tg_lds[i] = tglobal[i];
     __syncthreads();  // the only barrier
 
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -47,10 +46,10 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
     const uint32_t mt_per_page = mtx * n_rows;
     const uint32_t total_mt = mt_per_page * n_pages;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    const uint32_t n_waves = gridDim.x * V2_WAVES;
+    const uint32_t n_waves = gridDim.x * NW;
 
     v4i afrag[MT][KSTEPS];
-    for (uint32_t item = blockIdx.x * V2_WAVES + w; item < n_items; item += n_waves) {
+    for (uint32_t item = blockIdx.x * NW + w; item < n_items; item += n_waves) {
         // (page, row, column) of the item's first M-tile; the others follow by increment-with-carry
         uint32_t m0 = item * MT;
         uint32_t page = m0 / mt_per_page, rem = m0 % mt_per_page, row = rem / mtx, col = rem % mtx;
@@ -71,20 +70,18 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
             }
         }
 
-        // C-in: lane (r, g) owns output rows 4g..4g+3 (windows px+4g+i) of every M-tile
+        // C-in of the first segment: lane (r, g) owns output rows 4g..4g+3 (windows px+4g+i) of every M-tile.
+        // Unconditional loads (addresses are clamped) + arithmetic select: no branch, no wait between them.
+        size_t loff[MT];
         v4i nl[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)  // unconditional loads (addresses are clamped): no branch, no wait between them
-            nl[mt] = *reinterpret_cast<const v4i *>(negL + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + 4 * g);
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {  // M-tiles past the end of the enumeration: arithmetic select, never a branch
-            const int keep = pv[mt] ? -1 : 0;
-            nl[mt] = (nl[mt] & keep) | (v4i{-REJECT, -REJECT, -REJECT, -REJECT} & ~keep);
+        for (int mt = 0; mt < MT; mt++) {
+            loff[mt] = ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + 4 * g;
+            nl[mt] = *reinterpret_cast<const v4i *>(segs.s[0].negL + loff[mt]);
         }
-
         // A fragments: lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r.
         // Byte-unaligned 16-byte (8-byte) global loads land directly in the MFMA operand registers.
-        if (!(dbg & 2) || item == blockIdx.x * V2_WAVES + w)
+        if (!(dbg & 2) || item == blockIdx.x * NW + w)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + ((dbg & 4) ? 0 : r);
@@ -116,12 +113,30 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {  // M-tiles past the end of the enumeration never flag
+            const int keep = pv[mt] ? -1 : 0;
+            nl[mt] = (nl[mt] & keep) | (v4i{-REJECT, -REJECT, -REJECT, -REJECT} & ~keep);
+        }
         // B fragments of N-tile nt are in registers before the tile starts; each one is re-loaded for
         // N-tile nt+1 right after its last MFMA has issued, so the LDS latency hides behind the other K-steps.
         v4i bf[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = bank[ks * 64 + lane];
-        for (uint32_t nt = 0; nt < n_tiles16; nt++) {
+        uint32_t nt = 0;
+        for (uint32_t sgi = 0; sgi < segs.n; sgi++) {  // one segment = the N-tiles of one size class
+            const uint32_t seg_end = segs.s[sgi].tile_end;
+            if (sgi) {  // next size class of the pass -> its C-in table (scalar loads stay outside the N-tile loop)
+                const int32_t *tab = segs.s[sgi].negL;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) nl[mt] = *reinterpret_cast<const v4i *>(tab + loff[mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const int keep = pv[mt] ? -1 : 0;
+                    nl[mt] = (nl[mt] & keep) | (v4i{-REJECT, -REJECT, -REJECT, -REJECT} & ~keep);
+                }
+            }
+        for (; nt < seg_end; nt++) {
             v4i acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) acc[mt] = nl[mt];
@@ -132,17 +147,22 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
                 for (int mt = 0; mt < MT; mt++)
                     acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[mt][ks], bf[ks], acc[mt], 0, 0, 0);
                 bf[ks] = bank[(nxt * KSTEPS + ks) * 64 + lane];
+                // pin the re-load here: left alone, hipcc sinks all of them behind the last K-step and the
+                // next N-tile then opens with a full LDS round trip
+                __builtin_amdgcn_sched_barrier(0);
             }
-            int mm[MT];  // per-M-tile maximum of the lane's four outputs
+            // any output > 0 ?  two v_max3_i32 per M-tile; the per-M-tile split is redone on the rare path only
+            int m = max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3]));
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) mm[mt] = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
-            int m = mm[0];
-#pragma unroll
-            for (int mt = 1; mt < MT; mt++) m = max(m, mm[mt]);
+            for (int mt = 1; mt < MT; mt++) {
+                m = max(max(m, acc[mt][0]), acc[mt][1]);
+                m = max(max(m, acc[mt][2]), acc[mt][3]);
+            }
             if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    if (__builtin_amdgcn_ballot_w64(mm[mt] > 0) == 0) continue;  // wave-uniform
+                    const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
+                    if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const bool f = acc[mt][i] > 0;
@@ -173,45 +193,49 @@ __global__ __launch_bounds__(512, 2) void scan_mfma2_kernel(
                 }
             }
         }
+        }
     }
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
 }
 
-template <int KSTEPS, int RPG, int MT>
+template <int KSTEPS, int RPG, int MT, int NW>
 static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
-    const SizeClass &sc = *L.sc;
-    const uint32_t mtx = (uint32_t)((c->r_w - sc.n_w + 1 + 15) / 16);  // windows x in [0, r_w - n_w]
-    const uint32_t n_rows = (uint32_t)(c->r_h - sc.n_h);               // y in [1, r_h - n_h]
-    const uint32_t n_tiles16 = (L.chunk_n + 15) / 16;
-    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)V2_WAVES * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
+    const uint32_t mtx = (uint32_t)((c->r_w - L.min_w + 1 + 15) / 16);  // windows x in [0, r_w - min n_w]
+    const uint32_t n_rows = (uint32_t)(c->r_h - L.min_h);               // y in [1, r_h - min n_h]
+    const uint32_t n_tiles16 = L.n_tiles16;
+    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
     const uint64_t total_mt = (uint64_t)mtx * n_rows * c->n_pages;
     const uint64_t n_items = (total_mt + MT - 1) / MT;
-    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + V2_WAVES - 1) / V2_WAVES);
-    auto kern = scan_mfma2_kernel<KSTEPS, RPG, MT>;
+    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
+    auto kern = scan_mfma2_kernel<KSTEPS, RPG, MT, NW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + sc.q_offset + (size_t)(L.chunk_first / 16) * KSTEPS * 1024);
+    const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset);
     const uint64_t issued = n_items * MT * 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
-    const uint64_t alg = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * L.chunk_n * c->n_pages;
     uint32_t dbg = 0;  // FOCR_MFMA_DBG: timing experiments only (bit0: skip candidate emission, bit1: reuse first A fragments)
     if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
     char name[64];
-    snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d>", KSTEPS, RPG, MT);
-    c->launch_begin(name, L.chunk_n, alg, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, mtx,
-                       n_rows, (uint32_t)c->n_pages, qb, n_tiles16, L.chunk_n, L.negL, L.Lpitch, L.Lrows,
-                       c->d_tglobal + sc.first + L.chunk_first, (uint32_t)c->n_templates, c->d_cand,
-                       (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity, dbg);
+    snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
+    c->launch_begin(name, L.n_templates, L.alg_macs, issued);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, mtx,
+                       n_rows, (uint32_t)c->n_pages, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
+                       (uint32_t)c->n_templates, c->d_cand, (unsigned long long *)c->d_counter + 1,
+                       (unsigned long long)c->cand_capacity, dbg);
     c->launch_end();
     c->counters[3] += issued;
 }
 
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
-    const uint32_t ks = L.sc->k_groups / 4, rpg = L.sc->layout;
-    if ((uint64_t)((c->r_w - L.sc->n_w + 16) / 16) * (c->r_h - L.sc->n_h) * c->n_pages >= 0xffffffffull / 2)
+    const uint32_t ks = L.ksteps, rpg = L.layout;
+    if ((uint64_t)((c->r_w - L.min_w + 16) / 16) * (c->r_h - L.min_h) * c->n_pages >= 0xffffffffull / 2)
         return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
-#define CASE(K, R, M)                  \
-    case (K) * 10 + (R):               \
-        launch_v2<K, R, M>(c, L, n_cus); \
+    int cfg = 3;  // FOCR_MFMA_CFG: 3 = 16 waves x MT 4 (default, measured best), 0 = 8 waves x MT 8, 1 = 12 waves x MT 6, 2 = 12 waves x MT 8
+    if (const char *e = getenv("FOCR_MFMA_CFG")) cfg = atoi(e);
+#define CASE(K, R, M)                                                  \
+    case (K) * 10 + (R):                                               \
+        if (cfg == 1 && (K) <= 4) launch_v2<K, R, 6, 12>(c, L, n_cus);      \
+        else if (cfg == 2 && (K) <= 2) launch_v2<K, R, 8, 12>(c, L, n_cus); \
+        else if (cfg == 3 && (K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus); \
+        else launch_v2<K, R, M, 8>(c, L, n_cus);                       \
         break;
     switch (ks * 10 + rpg) {
         CASE(1, 1, 8) CASE(2, 1, 8) CASE(3, 1, 8) CASE(4, 1, 8) CASE(5, 1, 4) CASE(6, 1, 4) CASE(7, 1, 4) CASE(8, 1, 4)

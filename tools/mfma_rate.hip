@@ -1,0 +1,71 @@
+// microbenchmark: sustained v_mfma_i32_16x16x64_i8 issue rate in the prefilter's loop shape (tools only)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int MODE, int MT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void k(const v4i* __restrict__ src, int* __restrict__ out, int iters, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4i* bank = (v4i*)smem;
+    for (int i = threadIdx.x; i < ntiles * 3 * 64; i += NW * 64) bank[i] = src[i % 4096];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    v4i a[MT][3], nl[MT];
+    for (int mt = 0; mt < MT; mt++) { for (int ks = 0; ks < 3; ks++) a[mt][ks] = src[(threadIdx.x + 64 * (mt * 3 + ks)) % 4096]; nl[mt] = v4i{-1000000000, -1000000000, -1000000000, -1000000000}; }
+    int found = 0;
+    for (int it = 0; it < iters; it++) {
+        v4i bf[3];
+        for (int ks = 0; ks < 3; ks++) bf[ks] = bank[ks * 64 + lane];
+        for (int nt = 0; nt < ntiles; nt++) {
+            v4i acc[MT];
+            for (int mt = 0; mt < MT; mt++) acc[mt] = nl[mt];
+            const int nxt = nt + 1 < ntiles ? nt + 1 : nt;
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mt][ks], bf[ks], acc[mt], 0, 0, 0);
+                if (MODE >= 1) { bf[ks] = bank[(nxt * 3 + ks) * 64 + lane]; __builtin_amdgcn_sched_barrier(0); }
+            }
+            if (MODE >= 2) {
+                int m = acc[0][0];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) { m = max(m, max(acc[mt][0], acc[mt][1])); m = max(m, max(acc[mt][2], acc[mt][3])); }
+                if (__builtin_amdgcn_ballot_w64(m > 0)) found++;
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) asm volatile("" ::"v"(acc[mt]));
+            }
+        }
+    }
+    if (found == 12345) out[threadIdx.x] = found;
+}
+template <int MODE, int MT, int NW>
+void run(const v4i* d, int* o, const char* name) {
+    const int ntiles = 24, iters = 200;
+    size_t lds = ntiles * 3 * 1024;
+    auto kern = k<MODE, MT, NW>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, 0, d, o, iters, ntiles);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double mf = 256.0 * NW * iters * ntiles * 3 * MT;
+        if (rep == 2) printf("%s: %.3f ms, %.1f G MFMA/s, %.2f cycles/MFMA/SIMD @2.4GHz, %.1f TMAC/s\n", name, ms, mf / ms / 1e6, 1024 * 2.4e9 / (mf / (ms * 1e-3)), mf * 16384 / ms / 1e9);
+    }
+}
+int main() {
+    v4i* d; int* o; hipMalloc(&d, 4096 * 16); hipMalloc(&o, 4096);
+    unsigned* h = (unsigned*)malloc(4096 * 16); srand(1); for (int i = 0; i < 4096 * 4; i++) h[i] = rand() * 2654435761u;
+    hipMemcpy(d, h, 4096 * 16, hipMemcpyHostToDevice);
+    run<0, 8, 8>(d, o, "mfma only      MT8 NW8 ");
+    run<1, 8, 8>(d, o, "+ B reload     MT8 NW8 ");
+    run<2, 8, 8>(d, o, "+ max/ballot   MT8 NW8 ");
+    run<0, 4, 16>(d, o, "mfma only      MT4 NW16");
+    run<2, 4, 16>(d, o, "+ all          MT4 NW16");
+    run<2, 6, 12>(d, o, "+ all          MT6 NW12");
+    run<0, 8, 4>(d, o, "mfma only      MT8 NW4 ");
+    run<2, 8, 4>(d, o, "+ all          MT8 NW4 ");
+    return 0;
+}
