@@ -96,8 +96,9 @@ struct focr_ctx {
     uint64_t *d_hit_keys = nullptr, *d_hit_keys_alt = nullptr;
     float *d_hit_sims = nullptr, *d_hit_sims_alt = nullptr;
     uint32_t *d_counter = nullptr;  // [0] hits, [1] candidates, [2..] scratch
-    size_t cand_capacity = 0;
-    uint64_t *d_cand = nullptr;
+    size_t cand_capacity = 0, cand_alt_capacity = 0;
+    uint64_t *d_cand = nullptr, *d_cand_alt = nullptr;
+    bool ordered = false;  // the scan path already produced d_matches (MFMA path); order_hits is skipped
     int32_t *d_L = nullptr;  // prefilter thresholds [class][page][r_h][pitchL]
     size_t L_bytes = 0;
     void *d_sort_tmp = nullptr;
@@ -120,6 +121,7 @@ struct focr_ctx {
         void *ensure(focr_ctx *c, size_t want);
         void release();
     };
+    DevBuf scan_flags, scan_pos;
     DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
     bool lines_on_host = false;
     bool processed = false;

@@ -74,6 +74,10 @@ static void free_results(focr_ctx *c) {
     free_dev(c->d_hit_sims);
     free_dev(c->d_hit_sims_alt);
     free_dev(c->d_cand);
+    free_dev(c->d_cand_alt);
+    c->cand_alt_capacity = 0;
+    c->scan_flags.release();
+    c->scan_pos.release();
     free_dev(c->d_L);
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);
@@ -400,10 +404,13 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     }
     c->counters[2] = macs * c->n_pages;
     c->counters[3] = 0;
+    c->ordered = false;
     int rc = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
     if (rc) return rc;
-    rc = order_hits(c);
-    if (rc) return rc;
+    if (!c->ordered) {
+        rc = order_hits(c);
+        if (rc) return rc;
+    }
     c->scanned = true;
     return FOCR_OK;
 }

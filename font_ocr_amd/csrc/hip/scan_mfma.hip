@@ -31,6 +31,8 @@
 namespace focr {
 
 int ensure_hit_capacity(focr_ctx *c, size_t want);
+int sort_keys_u64(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned end_bit);
+int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos, size_t n);
 
 
 // ---------------------------------------------------------------------------------------------
@@ -120,15 +122,21 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
 // 3. exact verify: the reference arithmetic on every candidate
 typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
 
+// Candidates arrive sorted by key = (page*T + t, y, x): neighbouring lanes verify neighbouring windows of the same
+// template (cache-friendly), and the survivors are already in the reference's emission order, so no atomics and no
+// second sort: flag[i] / sim[i] are written in place and order.hip compacts them.
 __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, unsigned long long n_cand,
                                                      const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                      uint32_t n_total, const uint32_t *__restrict__ order_of,
                                                      const TemplateConst *__restrict__ tc, const v4i *__restrict__ needles16,
                                                      const uint32_t *__restrict__ needle16_row, double thr_d,
-                                                     uint64_t *__restrict__ hit_keys, float *__restrict__ hit_sims,
-                                                     unsigned long long *__restrict__ counter, unsigned long long capacity) {
+                                                     float *__restrict__ sims, uint64_t *__restrict__ flags) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cand) return;
+    if (i > n_cand) return;
+    if (i == n_cand) {  // sentinel so that the exclusive scan of flags also yields the total
+        flags[i] = 0;
+        return;
+    }
     const uint64_t key = cand[i];
     const uint32_t seg = (uint32_t)(key >> 32), page = seg / n_total, t = seg % n_total;
     const uint32_t x = (uint32_t)(key & 0xffff), y = (uint32_t)((key >> 16) & 0xffff);
@@ -154,13 +162,8 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
     }
     const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
     const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
-    if (ncc_emits(sim, thr_d)) {
-        unsigned long long idx = atomicAdd(counter, 1ull);
-        if (idx < capacity) {
-            hit_keys[idx] = key;
-            hit_sims[idx] = (float)sim;
-        }
-    }
+    sims[i] = (float)sim;
+    flags[i] = ncc_emits(sim, thr_d) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,20 +419,30 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             continue;
         }
         c->n_cand = (size_t)n_cand;
-        // 3. exact verify
-        if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, (size_t)n_cand)))) return rc;
-        if (n_cand) {
-            hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand,
-                               c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, (uint32_t)c->n_templates, c->d_order_of,
-                               c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_keys, c->d_hit_sims,
-                               (unsigned long long *)c->d_counter, (unsigned long long)c->hit_capacity);
-            FOCR_HIP(c, hipGetLastError());
+        // 3. sort the candidates into emission order, verify them exactly in place, compact + cap (order.hip)
+        if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, (size_t)n_cand + 1)))) return rc;
+        uint64_t *flags = (uint64_t *)c->scan_flags.ensure(c, ((size_t)n_cand + 1) * 8);
+        uint64_t *pos = (uint64_t *)c->scan_pos.ensure(c, ((size_t)n_cand + 1) * 8);
+        if (!flags || !pos) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
+        if (c->cand_alt_capacity < c->cand_capacity) {
+            FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_cand_alt) (void)hipFree(c->d_cand_alt);
+            c->d_cand_alt = nullptr;
+            c->cand_alt_capacity = 0;
+            if (hipMalloc(&c->d_cand_alt, c->cand_capacity * 8) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
+            c->cand_alt_capacity = c->cand_capacity;
         }
+        unsigned seg_bits = 1;
+        while (((uint64_t)1 << seg_bits) < (uint64_t)c->n_pages * c->n_templates) seg_bits++;
+        if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, (size_t)n_cand, 32 + seg_bits))) return rc;
+        hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((n_cand + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand,
+                           c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, (uint32_t)c->n_templates, c->d_order_of,
+                           c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_sims,
+                           flags);
+        FOCR_HIP(c, hipGetLastError());
         FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
-        unsigned long long n_hits = 0;
-        FOCR_HIP(c, hipMemcpyAsync(&n_hits, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipStreamSynchronize(c->stream));
-        c->n_hits_raw = (size_t)n_hits;  // <= n_cand <= hit_capacity
+        if ((rc = order_sorted_candidates(c, c->d_cand, c->d_hit_sims, flags, pos, (size_t)n_cand))) return rc;
+        const unsigned long long n_hits = c->n_hits_raw;
         FOCR_HIP(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
         FOCR_HIP(c, hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]));
         FOCR_HIP(c, hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[3]));
