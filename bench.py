@@ -56,6 +56,7 @@ def main():
     from font_ocr_amd import Bank, synth_pages
     from font_ocr_amd.bank import HIT_DTYPE
     from font_ocr_amd.searcher import SCAN_DIRECT, SCAN_MFMA, Scanner
+    from font_ocr_amd.shard import gather_chars
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -85,16 +86,8 @@ def main():
         ptr, cnt = sc.device_chars()
         nbytes = cnt * HIT_DTYPE.itemsize
         mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev) if nbytes else torch.zeros(0, dtype=torch.uint8, device=dev)
-        n = torch.tensor([nbytes], device=dev, dtype=torch.int64)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(max(sizes), 1)
-        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        buf[:nbytes] = mine
-        out = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, out, dst=0)
-        return sum(sizes) // HIT_DTYPE.itemsize if rank == 0 else 0
+        allc = gather_chars(mine, rank, world, dev)
+        return allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
 
     def step():
         sc.scan(args.threshold, 1024, mode)

@@ -1,0 +1,333 @@
+// ncc — the reference's `ncc` command line (src/ncc.rs:486-542, 788-878) on top of the MI355X scan.
+//
+// Same flags, defaults and output formats as the reference binary (clap derive struct `Args`,
+// src/ncc.rs:486-542).  Differences, all deliberate:
+//   * the template bank is rasterised once per run, not once per page (src/ncc.rs:561, 587-639);
+//   * pages of equal size are scanned as one device batch instead of one rayon task per page
+//     (src/ncc.rs:839-847); output order is still the order of -i;
+//   * --rust selects the exact v_dot4 device path (FOCR_SCAN_DIRECT) instead of the reference's scalar
+//     Rust scan (src/ncc.rs:406-483) — both are "the other implementation" used for A/B checks;
+//   * a page without any hit prints nothing (the reference panics in partition_by, src/ncc.rs:1040).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include "focr_host.h"
+
+namespace {
+
+const char *DEFAULT_ALPHABET = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789=+<>(){};:/-";  // src/ncc.rs:28-29
+
+struct Args {
+    std::vector<std::string> img;
+    std::string font;
+    float text_size = 0.f;
+    bool have_text_size = false;
+    uint32_t x_bits = 0, y_bits = 0;
+    bool hinting = false;
+    float threshold = 0.8f, anchor_threshold = 0.95f;
+    int overlap = 5;
+    std::string alphabet = DEFAULT_ALPHABET;
+    std::string box_size = "alphabet";
+    uint32_t x_padding = 0, y_padding = 0;
+    bool save_letters = false, rust = false, verbose = false, csv = false, raw = false;
+};
+
+[[noreturn]] void usage_error(const std::string &msg) {
+    fprintf(stderr, "error: %s\n\nUsage: ncc [OPTIONS] --font <FONT> --text-size <TEXT_SIZE>\n\nFor more information, try '--help'.\n", msg.c_str());
+    exit(2);  // clap's usage-error exit code
+}
+
+void print_help() {
+    puts("Usage: ncc [OPTIONS] --font <FONT> --text-size <TEXT_SIZE>\n\nOptions:\n"
+         "  -i, --img <IMG>...                         \n"
+         "  -f, --font <FONT>                          \n"
+         "  -t, --text-size <TEXT_SIZE>                \n"
+         "      --x-bits <X_BITS>                      [default: 0]\n"
+         "      --y-bits <Y_BITS>                      [default: 0]\n"
+         "      --hinting                              \n"
+         "      --threshold <THRESHOLD>                [default: 0.8]\n"
+         "      --anchor-threshold <ANCHOR_THRESHOLD>  [default: 0.95]\n"
+         "      --overlap <OVERLAP>                    [default: 5]\n"
+         "  -a, --alphabet <ALPHABET>                  [default: ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789=+<>(){};:/-]\n"
+         "      --box-size <BOX_SIZE>                  [default: alphabet]\n"
+         "      --x-padding <X_PADDING>                [default: 0]\n"
+         "      --y-padding <Y_PADDING>                [default: 0]\n"
+         "      --save-letters                         \n"
+         "      --rust                                 \n"
+         "  -v, --verbose                              \n"
+         "      --csv                                  \n"
+         "      --raw                                  \n"
+         "  -h, --help                                 Print help\n"
+         "  -V, --version                              Print version");
+}
+
+Args parse_args(int argc, char **argv) {
+    Args a;
+    std::vector<std::string> v(argv + 1, argv + argc);
+    auto is_opt = [](const std::string &s) { return s.size() > 1 && s[0] == '-' && !(isdigit((unsigned char)s[1]) || s[1] == '.'); };
+    for (size_t i = 0; i < v.size(); i++) {
+        std::string k = v[i], val;
+        bool has_val = false;
+        if (k.rfind("--", 0) == 0) {
+            size_t eq = k.find('=');
+            if (eq != std::string::npos) {
+                val = k.substr(eq + 1);
+                k = k.substr(0, eq);
+                has_val = true;
+            }
+        } else if (k.size() > 2 && k[0] == '-' && k[1] != '-') {  // -t13, -ipage.pgm
+            val = k.substr(k[2] == '=' ? 3 : 2);
+            k = k.substr(0, 2);
+            has_val = true;
+        }
+        auto need = [&]() -> std::string {
+            if (has_val) return val;
+            if (i + 1 >= v.size()) usage_error("a value is required for '" + k + "' but none was supplied");
+            return v[++i];
+        };
+        auto num_u = [&](const std::string &s) -> uint32_t {
+            char *e = nullptr;
+            unsigned long r = strtoul(s.c_str(), &e, 10);
+            if (!e || *e || s.empty() || s[0] == '-') usage_error("invalid value '" + s + "' for '" + k + "'");
+            return (uint32_t)r;
+        };
+        auto num_f = [&](const std::string &s) -> float {
+            char *e = nullptr;
+            float r = strtof(s.c_str(), &e);
+            if (!e || *e || s.empty()) usage_error("invalid value '" + s + "' for '" + k + "'");
+            return r;
+        };
+        if (k == "-i" || k == "--img") {
+            a.img.push_back(need());
+            while (i + 1 < v.size() && !is_opt(v[i + 1])) a.img.push_back(v[++i]);  // num_args = 1..
+        } else if (k == "-f" || k == "--font") a.font = need();
+        else if (k == "-t" || k == "--text-size") a.text_size = num_f(need()), a.have_text_size = true;
+        else if (k == "--x-bits") a.x_bits = num_u(need());
+        else if (k == "--y-bits") a.y_bits = num_u(need());
+        else if (k == "--hinting") a.hinting = true;
+        else if (k == "--threshold") a.threshold = num_f(need());
+        else if (k == "--anchor-threshold") a.anchor_threshold = num_f(need());
+        else if (k == "--overlap") {
+            std::string s = need();
+            char *e = nullptr;
+            long r = strtol(s.c_str(), &e, 10);
+            if (!e || *e || s.empty()) usage_error("invalid value '" + s + "' for '--overlap <OVERLAP>'");
+            a.overlap = (int)r;
+        } else if (k == "-a" || k == "--alphabet") a.alphabet = need();
+        else if (k == "--box-size") a.box_size = need();
+        else if (k == "--x-padding") a.x_padding = num_u(need());
+        else if (k == "--y-padding") a.y_padding = num_u(need());
+        else if (k == "--save-letters") a.save_letters = true;
+        else if (k == "--rust") a.rust = true;
+        else if (k == "-v" || k == "--verbose") a.verbose = true;
+        else if (k == "--csv") a.csv = true;
+        else if (k == "--raw") a.raw = true;
+        else if (k == "-h" || k == "--help") {
+            print_help();
+            exit(0);
+        } else if (k == "-V" || k == "--version") {
+            puts("ncc 0.1.0");
+            exit(0);
+        } else usage_error("unexpected argument '" + v[i] + "' found");
+    }
+    if (a.font.empty()) usage_error("the following required arguments were not provided:\n  --font <FONT>");
+    if (!a.have_text_size) usage_error("the following required arguments were not provided:\n  --text-size <TEXT_SIZE>");
+    return a;
+}
+
+std::vector<uint32_t> utf8_decode(const std::string &s) {
+    std::vector<uint32_t> out;
+    for (size_t i = 0; i < s.size();) {
+        unsigned char c = (unsigned char)s[i];
+        uint32_t cp;
+        int n;
+        if (c < 0x80) cp = c, n = 1;
+        else if ((c >> 5) == 6) cp = c & 0x1f, n = 2;
+        else if ((c >> 4) == 14) cp = c & 0x0f, n = 3;
+        else cp = c & 0x07, n = 4;
+        for (int k = 1; k < n && i + k < s.size(); k++) cp = (cp << 6) | ((unsigned char)s[i + k] & 0x3f);
+        out.push_back(cp);
+        i += n;
+    }
+    return out;
+}
+
+std::string utf8_encode(uint32_t cp) {
+    std::string s;
+    if (cp < 0x80) s += (char)cp;
+    else if (cp < 0x800) s += (char)(0xc0 | (cp >> 6)), s += (char)(0x80 | (cp & 0x3f));
+    else if (cp < 0x10000) s += (char)(0xe0 | (cp >> 12)), s += (char)(0x80 | ((cp >> 6) & 0x3f)), s += (char)(0x80 | (cp & 0x3f));
+    else s += (char)(0xf0 | (cp >> 18)), s += (char)(0x80 | ((cp >> 12) & 0x3f)), s += (char)(0x80 | ((cp >> 6) & 0x3f)), s += (char)(0x80 | (cp & 0x3f));
+    return s;
+}
+
+std::string f32s(float v) {  // Rust `{}` of an f32
+    char buf[64];
+    focr_format_f32(v, buf, sizeof buf);
+    return buf;
+}
+
+// --save-letters: letters/{letter}-{x}_{y}.png, 8-bit grey (src/ncc.rs:642-649)
+bool write_png_gray(const std::string &path, const uint8_t *px, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> raw((size_t)(w + 1) * h);
+    for (uint32_t y = 0; y < h; y++) {
+        raw[(size_t)y * (w + 1)] = 0;
+        memcpy(&raw[(size_t)y * (w + 1) + 1], px + (size_t)y * w, w);
+    }
+    uLongf zl = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zl);
+    if (compress2(z.data(), &zl, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto be32 = [](uint8_t *p, uint32_t v) { p[0] = v >> 24, p[1] = v >> 16, p[2] = v >> 8, p[3] = v; };
+    auto chunk = [&](const char *type, const uint8_t *data, uint32_t len) {
+        uint8_t hdr[8];
+        be32(hdr, len);
+        memcpy(hdr + 4, type, 4);
+        fwrite(hdr, 1, 8, f);
+        if (len) fwrite(data, 1, len, f);
+        uLong crc = crc32(0, (const Bytef *)type, 4);
+        if (len) crc = crc32(crc, data, len);
+        uint8_t c[4];
+        be32(c, (uint32_t)crc);
+        fwrite(c, 1, 4, f);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13] = {0};
+    be32(ihdr, w);
+    be32(ihdr + 4, h);
+    ihdr[8] = 8;  // bit depth, colour type 0 (grey)
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (uint32_t)zl);
+    chunk("IEND", nullptr, 0);
+    fclose(f);
+    return true;
+}
+
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "ncc: %s\n", msg.c_str());
+    exit(101);  // a Rust panic's exit status
+}
+
+#define CK(ctx, expr)                                                        \
+    do {                                                                     \
+        if ((expr) != FOCR_OK) die(std::string(#expr) + ": " + focr_last_error(ctx)); \
+    } while (0)
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Args args = parse_args(argc, argv);
+    int box = args.box_size == "font" ? FOCR_BOX_FONT : args.box_size == "alphabet" ? FOCR_BOX_ALPHABET : args.box_size == "char" ? FOCR_BOX_CHAR : -1;
+    if (box < 0) die("called `Result::unwrap()` on an `Err` value: () (--box-size must be font, alphabet or char)");  // src/ncc.rs:559
+    if (args.raw && args.img.size() != 1) die("assertion failed: args.img.len() == 1");  // src/ncc.rs:834
+
+    // template bank, once (get_hits re-does this per page: src/ncc.rs:561, 587-639)
+    std::vector<uint32_t> alphabet = utf8_decode(args.alphabet);
+    focr_bank_t bank{};
+    char err[256] = {0};
+    if (focr_raster_bank(args.font.c_str(), args.text_size, args.x_bits, args.y_bits, args.hinting, alphabet.data(), alphabet.size(),
+                         box, args.x_padding, args.y_padding, &bank, err, sizeof err) != 0)
+        die(std::string("rasterising the template bank failed: ") + err);
+    if (args.verbose) {
+        fprintf(stderr, "bank: %zu templates (%zu letters x %u x %u sub-pixel offsets), advance %spx\n", bank.n_templates,
+                alphabet.size(), 1u << args.x_bits, 1u << args.y_bits, f32s(bank.advance_px).c_str());
+    }
+    for (size_t t = 0; t < bank.n_templates; t++)
+        if (bank.templates[t].n_w > 16) die("not handled");  // src/ncc.rs:392
+    if (args.save_letters) {
+        mkdir("letters", 0777);
+        for (size_t t = 0; t < bank.n_templates; t++) {
+            const focr_template_t &d = bank.templates[t];
+            std::string path = "letters/" + utf8_encode(d.letter) + "-" + std::to_string((size_t)(d.off_x * 1000.f)) + "_" +
+                               std::to_string((size_t)(d.off_y * 1000.f)) + ".png";
+            if (!write_png_gray(path, bank.needles + d.offset, d.n_w, d.n_h)) die("cannot write " + path);
+        }
+    }
+    if (args.img.empty()) return 0;
+
+    // pages, grouped by size so that each group is one resident device batch
+    struct Page {
+        uint8_t *px = nullptr;
+        size_t w = 0, h = 0;
+    };
+    std::vector<Page> pages(args.img.size());
+    std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
+    for (size_t i = 0; i < args.img.size(); i++) {
+        if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, err, sizeof err) != 0)
+            die(std::string("cannot open image: ") + err);  // image::open(..).unwrap(), src/ncc.rs:575
+        groups[{pages[i].w, pages[i].h}].push_back(i);
+    }
+
+    focr_ctx_t *ctx = nullptr;
+    if (focr_ctx_create(0, &ctx) != FOCR_OK) die(std::string("no usable GPU: ") + focr_last_error_global());
+    CK(ctx, focr_bank_upload(ctx, bank.templates, bank.n_templates, bank.needles, bank.needles_len));
+    const int mode = args.rust ? FOCR_SCAN_DIRECT : FOCR_SCAN_MFMA;
+
+    std::vector<std::vector<std::vector<focr_hit_t>>> page_lines(args.img.size());  // [page][line][char]
+    for (auto &kv : groups) {
+        const size_t w = kv.first.first, h = kv.first.second;
+        const std::vector<size_t> &idx = kv.second;
+        CK(ctx, focr_pages_alloc(ctx, idx.size(), w, h));
+        for (size_t k = 0; k < idx.size(); k++) CK(ctx, focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
+        CK(ctx, focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
+        const size_t T = bank.n_templates, n_seg = idx.size() * T;
+        std::vector<uint64_t> off(n_seg + 1);
+        std::vector<focr_match_t> m(focr_total_matches(ctx));
+        CK(ctx, focr_get_matches(ctx, off.data(), m.data()));
+        for (size_t s = 0; s < n_seg; s++)
+            if (off[s + 1] - off[s] == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+        if (args.verbose) {
+            float ms[6];
+            focr_last_timings(ctx, ms);
+            fprintf(stderr, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5], m.size());
+        }
+        if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order, then exit
+            for (size_t t = 0; t < T; t++) {
+                const focr_template_t &d = bank.templates[t];
+                for (uint64_t q = off[t]; q < off[t + 1]; q++) {
+                    float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
+                    printf("%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x, m[q].y, d.n_w,
+                           d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str());
+                }
+            }
+            return 0;
+        }
+        CK(ctx, focr_process_hits(ctx, args.anchor_threshold, args.overlap));
+        std::vector<uint64_t> page_off(idx.size() + 1), line_off(focr_total_lines(ctx) + 1);
+        std::vector<focr_hit_t> chars(focr_total_chars(ctx));
+        CK(ctx, focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
+        for (size_t k = 0; k < idx.size(); k++)
+            for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++)
+                page_lines[idx[k]].emplace_back(chars.begin() + line_off[l], chars.begin() + line_off[l + 1]);
+    }
+
+    // output, src/ncc.rs:849-877
+    for (size_t i = 0; i < page_lines.size(); i++)
+        for (auto &line : page_lines[i]) {
+            if (args.csv) {
+                for (auto &c : line) {
+                    float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
+                    printf("%zu,%u,%s,%s,%u,%u,%u,%u\n", i, c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x, c.y, c.w, c.h);
+                }
+            } else {
+                std::string s;
+                for (auto &c : line) s += utf8_encode(c.letter);
+                puts(s.c_str());
+            }
+        }
+    focr_ctx_destroy(ctx);
+    for (auto &p : pages) free(p.px);
+    focr_bank_free(&bank);
+    return 0;
+}

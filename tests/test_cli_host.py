@@ -1,0 +1,84 @@
+"""Host-side pieces around the scan: the `ncc` CLI surface (src/ncc.rs:486-542), Rust-compatible float
+printing, image decode.  The GPU end-to-end CLI test is in test_gpu_cli.py."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from font_ocr_amd import load_image, save_pgm
+from font_ocr_amd.bank import format_f32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCC = os.path.join(ROOT, "font_ocr_amd", "bin", "ncc")
+
+
+@pytest.fixture(scope="module")
+def ncc_bin():
+    if not os.path.exists(NCC):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "font_ocr_amd", "csrc"), "cli"], check=True)
+    return NCC
+
+
+def test_format_f32_matches_rust_display():
+    # values as Rust's `{}` prints f32 (shortest round-trip, no exponent, no trailing ".0")
+    for v, want in [(12.5, "12.5"), (12.0, "12"), (0.1, "0.1"), (304.0, "304"), (7.5, "7.5"), (0.25, "0.25"),
+                    (1e-7, "0.0000001"), (16777216.0, "16777216"), (-3.5, "-3.5"), (0.0, "0"), (1.0 / 3.0, "0.33333334"),
+                    (0.8, "0.8"), (7.8266602, "7.82666")]:
+        assert format_f32(np.float32(v)) == want, (v, format_f32(np.float32(v)))
+
+
+def test_cli_flags_and_errors(ncc_bin):
+    r = subprocess.run([ncc_bin, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for flag in ("--img", "--font", "--text-size", "--x-bits", "--y-bits", "--hinting", "--threshold", "--anchor-threshold",
+                 "--overlap", "--alphabet", "--box-size", "--x-padding", "--y-padding", "--save-letters", "--rust", "--verbose",
+                 "--csv", "--raw"):
+        assert flag in r.stdout, flag
+    assert "[default: 0.8]" in r.stdout and "[default: 0.95]" in r.stdout and "[default: 5]" in r.stdout
+    r = subprocess.run([ncc_bin, "-t", "13"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--font <FONT>" in r.stderr  # clap: missing required argument
+    r = subprocess.run([ncc_bin, "-f", "x.ttf"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--text-size" in r.stderr
+    r = subprocess.run([ncc_bin, "-f", "x.ttf", "-t", "13", "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
+    r = subprocess.run([ncc_bin, "-f", "/nonexistent.ttf", "-t", "13"], capture_output=True, text=True)
+    assert r.returncode == 101  # Font::from_path(..).unwrap() panics, src/ncc.rs:561
+
+
+def test_pnm_and_png_decode(tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (17, 23), dtype=np.uint8)
+    save_pgm(tmp_path / "a.pgm", img)
+    assert np.array_equal(load_image(tmp_path / "a.pgm"), img)
+    # P6: rgb -> luma with the image crate's weights
+    rgb = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    with open(tmp_path / "b.ppm", "wb") as f:
+        f.write(b"P6\n# comment\n7 5\n255\n" + rgb.tobytes())
+    r32 = rgb.astype(np.uint32)
+    want = ((2126 * r32[..., 0] + 7152 * r32[..., 1] + 722 * r32[..., 2]) // 10000).astype(np.uint8)
+    assert np.array_equal(load_image(tmp_path / "b.ppm"), want)
+    # P2 ascii
+    with open(tmp_path / "c.pgm", "w") as f:
+        f.write("P2\n3 2\n255\n0 128 255\n1 2 3\n")
+    assert load_image(tmp_path / "c.pgm").tolist() == [[0, 128, 255], [1, 2, 3]]
+
+    def png(data, w, h, depth, ctype, filt_rows):
+        def chunk(t, d):
+            return len(d).to_bytes(4, "big") + t + d + zlib.crc32(t + d).to_bytes(4, "big")
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([depth, ctype, 0, 0, 0]))
+                + chunk(b"IDAT", zlib.compress(filt_rows)) + chunk(b"IEND", b""))
+
+    # 8-bit grey with Sub and Up filters
+    raw = bytearray()
+    for y in range(img.shape[0]):
+        row = img[y].astype(np.int32)
+        if y % 2 == 0:
+            raw += bytes([1]) + bytes(((row - np.concatenate([[0], row[:-1]])) % 256).astype(np.uint8))
+        else:
+            raw += bytes([2]) + bytes(((row - img[y - 1].astype(np.int32)) % 256).astype(np.uint8))
+    (tmp_path / "d.png").write_bytes(png(None, img.shape[1], img.shape[0], 8, 0, bytes(raw)))
+    assert np.array_equal(load_image(tmp_path / "d.png"), img)
+    with pytest.raises(OSError):
+        load_image(tmp_path / "missing.png")

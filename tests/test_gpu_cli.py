@@ -1,0 +1,71 @@
+"""End-to-end `ncc` CLI on the GPU: default text output, --csv, --raw against the oracle pipeline."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from font_ocr_amd import ASCII95, Bank, save_pgm, synth_page
+from font_ocr_amd.bank import SYNTH_SEED_BASE, format_f32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCC = os.path.join(ROOT, "font_ocr_amd", "bin", "ncc")
+FONT = "/usr/share/fonts/truetype/dejavu/DejaVuSansMono.ttf"
+
+
+@pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")
+def test_cli_text_csv_raw(tmp_path):
+    if not os.path.exists(NCC):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "font_ocr_amd", "csrc"), "cli"], check=True)
+    alphabet = ASCII95[1:60]  # no space
+    bank = Bank.rasterize(FONT, 13, 1, 0, alphabet=alphabet)
+    pages = [synth_page(bank, SYNTH_SEED_BASE + 400 + p, 300 + 20 * (p % 2), 130) for p in range(3)]  # two page sizes
+    paths = []
+    for p, pg in enumerate(pages):
+        paths.append(str(tmp_path / f"p{p}.pgm"))
+        save_pgm(paths[-1], pg)
+    common = [NCC, "-f", FONT, "-t", "13", "--x-bits", "1", "-a", alphabet]
+    want_lines = []
+    want_raw0 = None
+    for p, pg in enumerate(pages):
+        counts, matches = O.scan_page(O.invert(pg), bank, 0.8, use_ref=O.have_ref())
+        hits = O.raw_hits(counts, matches, bank)
+        if p == 0:
+            want_raw0 = (counts, matches)
+        want_lines.append(O.process_hits(hits, 0.95, 5))
+
+    r = subprocess.run(common + ["-i"] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want_text = "".join("".join(chr(int(c)) for c in l["letter"]) + "\n" for lines in want_lines for l in lines)
+    assert r.stdout == want_text
+    assert len(want_text) > 50
+
+    r = subprocess.run(common + ["--csv", "--rust", "-i"] + paths, capture_output=True, text=True)  # --rust = direct device path
+    assert r.returncode == 0, r.stderr
+    want_csv = []
+    for p, lines in enumerate(want_lines):
+        for l in lines:
+            for c in l:
+                cx, cy = np.float32(c["x"]) + np.float32(c["w"]) * np.float32(0.5), np.float32(c["y"]) + np.float32(c["h"]) * np.float32(0.5)
+                want_csv.append(f"{p},{int(c['letter'])},{format_f32(cx)},{format_f32(cy)},{int(c['x'])},{int(c['y'])},{int(c['w'])},{int(c['h'])}")
+    assert r.stdout.splitlines() == want_csv
+
+    r = subprocess.run(common + ["--raw", "-i", paths[0]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    counts, matches = want_raw0
+    rows = r.stdout.splitlines()
+    assert len(rows) == int(counts.sum())
+    k = 0
+    for t in range(len(counts)):
+        d = bank.templates[t]
+        for m in matches[t, : counts[t]]:
+            f = rows[k].split(",")
+            assert [int(f[0]), int(f[3]), int(f[4]), int(f[5]), int(f[6])] == [int(d["letter"]), int(m["x"]), int(m["y"]), int(d["n_w"]), int(d["n_h"])]
+            assert f[1] == format_f32(np.float32(m["x"]) + np.float32(d["n_w"]) * np.float32(0.5))
+            assert f[9] == format_f32(d["off_x"]) and f[10] == format_f32(d["off_y"])
+            k += 1
+    r = subprocess.run(common + ["--raw", "-i"] + paths, capture_output=True, text=True)
+    assert r.returncode == 101  # assert!(args.img.len() == 1), src/ncc.rs:834
