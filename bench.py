@@ -32,6 +32,17 @@ R_W, R_H = 608, 720
 PEAK_I8_MFMA_TOPS = 5000.0  # dense i8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
 
 
+def traffic_of(kernel_name):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md); None if the
+    file is absent or was taken for another kernel."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return t["traffic_bytes"] if t.get("kernel") == kernel_name else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,7 +174,7 @@ def main():
             "peak": PEAK_I8_MFMA_TOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4),
-            "traffic": None,
+            "traffic": traffic_of(name),
             "avg_kernel_ms": round(k["ms"] / k["n"], 4),
             "algorithmic_macs_per_launch": k["alg"],
             "issued_macs_per_launch": k["issued"],
