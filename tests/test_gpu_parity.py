@@ -204,3 +204,72 @@ def test_full_size_c2_properties(scanner, bank_x2):
             ok += by_y.get(y) == want
             tot += 1
     assert ok >= 0.9 * tot, (ok, tot)
+
+
+def _random_bank(rng, shapes, per_shape):
+    """A bank of random-noise / structured templates with the given (n_w, n_h) shapes (several size classes)."""
+    from font_ocr_amd.bank import TEMPLATE_DTYPE, Bank
+
+    tm, needles, off = [], [], 0
+    for (w, h) in shapes:
+        for k in range(per_shape):
+            if k % 3 == 0:
+                nd = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            elif k % 3 == 1:  # sparse strokes
+                nd = np.zeros((h, w), np.uint8)
+                nd[rng.integers(0, h, 3 + h), rng.integers(0, w, 3 + h)] = rng.integers(100, 256, 3 + h)
+            else:  # constant (never emits) or nearly constant
+                nd = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+                if k % 2:
+                    nd[0, 0] ^= 1
+            t = np.zeros(1, TEMPLATE_DTYPE)
+            t["letter"], t["n_w"], t["n_h"], t["offset"] = 65 + len(tm) % 26, w, h, off
+            tm.append(t)
+            needles.append(nd.reshape(-1))
+            off += nd.size
+    return Bank(np.concatenate(tm), np.concatenate(needles), len(tm), 0, 0, 13.0, 8.0)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("shapes", [
+    [(16, 16), (13, 7), (14, 20)],            # 16-byte-row layout, 4 / 2 / 5 K-steps
+    [(8, 15), (5, 9), (3, 3), (1, 1), (8, 32)],  # 8-byte rows only (no 9..12-wide class present)
+    [(9, 15), (8, 15), (12, 16), (10, 3)],     # 12-byte rows shared by narrow classes
+    [(9, 17), (11, 32), (4, 30), (16, 32)],    # tall templates: 6 / 8 K-steps
+], ids=["w16", "w8", "w12", "tall"])
+def test_random_banks_all_layouts(scanner, mode, shapes):
+    rng = np.random.default_rng(hash(str(shapes)) % 2**32)
+    bank = _random_bank(rng, shapes, 7)
+    pages = rng.integers(0, 256, (2, 61, 97), dtype=np.uint8)
+    # plant a few templates so that high-similarity hits exist too
+    for k, t in enumerate(range(0, len(bank), 5)):
+        nd = bank.needle(t)
+        y, x = 2 + 3 * k % 20, 1 + 11 * k % 60
+        pages[0, y:y + nd.shape[0], x:x + nd.shape[1]] = 255 - nd[: 61 - y, : 97 - x]
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    for thr in (0.25, 0.9):
+        scanner.scan(thr, 1024, mode)
+        offsets, m = scanner.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), _oracle_lists(pages, bank, thr, 1024), f"{shapes} thr={thr}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_c3_bank_16_shifts(scanner, bank_x2y2, mode):
+    """configs[2] bank: 95 glyphs x 16 sub-pixel shifts = 1520 templates in four size classes."""
+    pages = np.stack([synth_page(bank_x2y2, SYNTH_SEED_BASE + 500 + p, 330, 120) for p in range(2)])
+    scanner.set_bank(bank_x2y2)
+    scanner.set_pages(pages)
+    scanner.scan(0.8, 1024, mode)
+    offsets, m = scanner.matches()
+    want = _oracle_lists(pages, bank_x2y2, 0.8, 1024)
+    _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2y2)), want, "c3 bank")
+    assert sum(len(x) for p in want for x in p) > 1000
+
+
+def test_wide_template_is_rejected(scanner):
+    from font_ocr_amd.searcher import FocrError
+
+    bank = _random_bank(np.random.default_rng(0), [(17, 5)], 1)
+    with pytest.raises(FocrError, match="wider than 16"):  # the reference panics: "not handled", src/ncc.rs:392
+        scanner.set_bank(bank)
