@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pages", type=int, default=0, help="0 = 4 pages per host thread")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,8 +72,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
@@ -103,14 +106,14 @@ def main():
     def step():
         sc.scan(args.threshold, 1024, mode)
         sc.process_hits(0.95, 5)
-        if world > 1:
+        if use_dist:
             return gather_lines()
         return sc.total_chars()
 
     def fence():
         sc.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +134,7 @@ def main():
             phase[k_] = phase.get(k_, 0.0) + v
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -208,7 +211,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     sc.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
