@@ -56,6 +56,12 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     args = ap.parse_args()
 
+    # Exactly ONE line may reach stdout (the JSON).  RCCL prints a version banner to stdout at init, so park
+    # the real stdout and point fd 1 at stderr for everything else (Python and native code alike).
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,7 +215,7 @@ def main():
         }
 
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     sc.close()
     if use_dist:
         dist.destroy_process_group()
