@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pages", type=int, default=0, help="0 = 4 pages per host thread")
+    ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
+    ap.add_argument("--with-upload", action="store_true", help="also time steps that start from host pages (PCIe-inclusive rate, reported as e2e_*)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -87,7 +89,10 @@ def main():
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
     P = args.pages_per_gpu
-    pages = synth_pages(bank, P, R_W, R_H, first=rank * P)  # every rank scans its own shard of the page set
+    if args.noise:
+        pages = np.random.default_rng(1234 + rank).integers(0, 256, (P, R_H, R_W), dtype=np.uint8)
+    else:
+        pages = synth_pages(bank, P, R_W, R_H, first=rank * P)  # every rank scans its own shard of the page set
 
     sc = Scanner(local_rank)
     sc.set_bank(bank)
@@ -147,6 +152,15 @@ def main():
 
     total_px = world * P * R_W * R_H * args.steps
     value = total_px / dt / 1e6
+    e2e = None
+    if args.with_upload:  # PCIe-inclusive: every step starts from pageable host memory (never the headline value)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sc.upload_pages(pages, 0, invert=True)
+            step()
+        fence()
+        e2e = total_px / (time.perf_counter() - t1) / 1e6
     counters = sc.counters()
 
     out = {
@@ -171,6 +185,10 @@ def main():
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
         },
     }
+    if e2e is not None:
+        out["e2e_value_incl_h2d"] = round(e2e, 2)
+    if args.noise:
+        out["data"] = "uniform random noise pages (worst case, no hits)"
     if rank == 0:
         # dominant kernel = the scan launch with the most algorithmic work
         name, k = max(kern.items(), key=lambda kv: kv[1]["alg"])

@@ -273,3 +273,20 @@ def test_wide_template_is_rejected(scanner):
     bank = _random_bank(np.random.default_rng(0), [(17, 5)], 1)
     with pytest.raises(FocrError, match="wider than 16"):  # the reference panics: "not handled", src/ncc.rs:392
         scanner.set_bank(bank)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_full_page_low_threshold_hits_the_cap(scanner, bank_x2, mode):
+    """A full 608x720 page at threshold 0.45: many templates exceed 1024 matches, so the reference's
+    "stop at n_out" (src/ncc.cpp:225-227) decides which (y, x) survive — lists must still be identical."""
+    page = synth_page(bank_x2, SYNTH_SEED_BASE + 3, 608, 720)
+    bank = bank_x2.subset(list(range(40, 60)) + list(range(95 + 40, 95 + 60)))
+    scanner.set_bank(bank)
+    scanner.set_pages(page)
+    scanner.scan(0.45, 1024, mode)
+    counts = scanner.counts()[0]
+    offsets, m = scanner.matches()
+    want = _oracle_lists(page[None], bank, 0.45, 1024)
+    _assert_same(_csr_to_lists(offsets, m, 1, len(bank)), want, "cap")
+    assert (counts == 1024).sum() >= 3, counts.max()  # the cap really was exercised
+    assert scanner.counters()["raw_hits"] > int(counts.sum())  # ... and some hits were cut off
