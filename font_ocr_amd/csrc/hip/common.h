@@ -39,6 +39,9 @@ struct SuperClass {
     std::vector<uint32_t> tile_first;  // first N-tile of each class inside the super-class
     uint32_t n_tiles;
     size_t q_offset, tg_offset;
+    // per scan: window enumeration of the pass (smallest searchable template) and its live-tile list
+    uint32_t min_w, min_h, mtx, n_rows;
+    size_t live_offset;
 };
 
 // Per-template constants, computed once on the host in IEEE double exactly as
@@ -121,7 +124,7 @@ struct focr_ctx {
         void *ensure(focr_ctx *c, size_t want);
         void release();
     };
-    DevBuf scan_flags, scan_pos;
+    DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
     DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
     bool lines_on_host = false;
     bool processed = false;

@@ -78,6 +78,8 @@ static void free_results(focr_ctx *c) {
     c->cand_alt_capacity = 0;
     c->scan_flags.release();
     c->scan_pos.release();
+    c->scan_live.release();
+    c->scan_live_list.release();
     free_dev(c->d_L);
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);

@@ -70,7 +70,10 @@ struct MfmaLaunch {
     size_t tg_offset;     // entry offset of the chunk's template ids in d_tglobal
     uint32_t n_tiles16;   // N-tiles in the chunk
     uint32_t n_templates; // real templates in the chunk
-    uint32_t min_w, min_h;  // smallest template of the chunk: defines the window enumeration
+    uint32_t mtx, n_rows;   // window enumeration of the pass: M-tiles per row, searched rows (y = 1 + row)
+    const uint64_t *live_list;   // packed (page << 32 | row << 12 | col) of the M-tiles that have something to scan
+    const uint32_t *live_count;  // device-side length of live_list
+    uint32_t super_index;
     MfmaSegs segs;
     uint32_t Lpitch, Lrows;
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)

@@ -52,7 +52,8 @@ constexpr int STX = 64, STY = 32, SLDW = 21, SMAXROWS = STY + 31;
 template <int NDW>
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                     uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, float kq,
-                                                    int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows) {
+                                                    int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows,
+                                                    uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
     __shared__ uint32_t tile[SMAXROWS][SLDW];
     __shared__ uint32_t H[SMAXROWS][STX];
     __shared__ uint32_t H2[SMAXROWS][STX];
@@ -109,6 +110,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
                 out = -(int32_t)Lf;
             }
+            // mark the 16-window M-tile as having something to scan (blank paper never does: the reference prunes
+            // it too, src/ncc.rs:280-301): one store per 16-lane group, decided by ballot
+            {
+                const uint64_t lm = __builtin_amdgcn_ballot_w64(out != -REJECT);
+                const uint32_t lane = threadIdx.x & 63;
+                if ((lane & 15) == 0 && ((lm >> lane) & 0xffffu) && y >= 1 && (y - 1) < n_rows && (x >> 4) < mtx)
+                    live[((size_t)page * n_rows + (y - 1)) * mtx + (x >> 4)] = 1;
+            }
             negL[((size_t)page * Lrows + y) * Lpitch + x] = out;
         }
         if (k + 1 < PER) {  // slide down one row
@@ -116,6 +125,47 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             s2 += H2[r0 + k + n_h][col] - H2[r0 + k][col];
         }
     }
+}
+
+// Live M-tiles -> packed work list (page << 32 | row << 12 | col).  A block compacts 4096 consecutive tiles
+// (16 per thread) with one global atomic, so the shared counter sees ~1 atomic per 4096 tiles.  The order of the
+// list does not matter for the results (every M-tile is independent; hits are sorted later).
+constexpr uint32_t CLT_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void compact_live_tiles(const uint8_t *__restrict__ live, uint32_t n_tiles, uint32_t mtx,
+                                                          uint32_t n_rows, uint32_t skip_blank, uint64_t *__restrict__ list,
+                                                          uint32_t *__restrict__ count) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t block_base;
+    const uint32_t first = (blockIdx.x * 256 + threadIdx.x) * CLT_PER_THREAD;
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CLT_PER_THREAD; k++) {
+        const uint32_t i = first + k;
+        if (i < n_tiles && (live[i] || !skip_blank)) bits |= 1u << k;
+    }
+    const uint32_t cnt = (uint32_t)__builtin_popcount(bits);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = cnt;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        block_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    uint32_t pos = block_base + incl - cnt;
+    for (uint32_t q = 0; q < wv; q++) pos += wave_tot[q];
+    for (uint32_t k = 0; k < CLT_PER_THREAD; k++)
+        if (bits & (1u << k)) {
+            const uint32_t i = first + k;
+            const uint32_t col = i % mtx, rowp = i / mtx, row = rowp % n_rows, page = rowp / n_rows;
+            list[pos++] = ((uint64_t)page << 32) | ((uint64_t)row << 12) | col;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,7 +353,8 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
 }
 
 template <int NDW>
-static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t *negL, uint32_t Lpitch, uint32_t Lrows) {
+static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t *negL, uint32_t Lpitch, uint32_t Lrows,
+                         uint8_t *live, uint32_t mtx, uint32_t n_rows) {
     dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->n_pages);
     // kq = kappa / sqrt(n), rounded toward -inf so that the f32 product never overshoots the true threshold
     const double kq_d = kappa / std::sqrt((double)(sc.n_w * sc.n_h));
@@ -311,7 +362,8 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
     if ((double)kq > kq_d) kq = std::nextafterf(kq, -INFINITY);
     kq = std::nextafterf(kq, -INFINITY);
     hipLaunchKernelGGL((stats_kernel<NDW>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
-                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows);
+                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
+                       n_rows);
 }
 
 int launch_scan_mfma(focr_ctx *c, float threshold) {
@@ -346,25 +398,61 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         c->launches_reset();
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
-        // 1. statistics
-        for (size_t k = 0; k < c->classes.size(); k++) {
-            const SizeClass &sc = c->classes[k];
-            if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
-            const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
-            const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
-            int32_t *negL = c->d_L + k * L_per_class;
-            switch (sc.ndw) {
-                case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows); break;
-                default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+        // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
+        uint32_t dbg = 0;
+        if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
+        size_t tiles_total = 0;
+        for (SuperClass &su : c->supers) {
+            su.min_w = su.min_h = 0xffffffffu;
+            for (uint32_t k : su.classes) {
+                const SizeClass &sc = c->classes[k];
+                if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
+                su.min_w = std::min(su.min_w, sc.n_w);
+                su.min_h = std::min(su.min_h, sc.n_h);
             }
+            su.mtx = su.n_rows = 0;
+            su.live_offset = tiles_total;
+            if (su.min_w == 0xffffffffu) continue;  // nothing searchable
+            su.mtx = (uint32_t)((c->r_w - su.min_w + 1 + 15) / 16);  // windows x in [0, r_w - min n_w]
+            su.n_rows = (uint32_t)(c->r_h - su.min_h);               // y in [1, r_h - min n_h]
+            const uint64_t nt = (uint64_t)su.mtx * su.n_rows * c->n_pages;
+            if (nt >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
+            tiles_total += (size_t)nt;
+        }
+        uint8_t *live = (uint8_t *)c->scan_live.ensure(c, tiles_total + 16);
+        uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
+        if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
+        FOCR_HIP(c, hipMemsetAsync(live, 0, tiles_total + 16, c->stream));
+        for (size_t si = 0; si < c->supers.size(); si++) {
+            const SuperClass &su = c->supers[si];
+            if (!su.mtx) continue;
+            for (uint32_t k : su.classes) {
+                const SizeClass &sc = c->classes[k];
+                if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
+                const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
+                const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
+                int32_t *negL = c->d_L + k * L_per_class;
+                uint8_t *lv = live + su.live_offset;
+                switch (sc.ndw) {
+                    case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                    case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                    case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                    case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                    default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+                }
+                FOCR_HIP(c, hipGetLastError());
+            }
+            const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->n_pages);
+            hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
+                               su.n_rows, (dbg & 8) ? 0u : 1u, live_list + su.live_offset, c->d_counter + 8 + si);
             FOCR_HIP(c, hipGetLastError());
         }
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
         // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget)
-        for (const SuperClass &su : c->supers) {
+        if (c->supers.size() > 40) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many super-classes");
+        for (size_t si = 0; si < c->supers.size(); si++) {
+            const SuperClass &su = c->supers[si];
+            if (!su.mtx) continue;
             const uint32_t chunk_tiles = (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
             uint32_t t0 = 0;
             while (t0 < su.n_tiles) {
@@ -373,7 +461,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.ksteps = su.ksteps;
                 L.Lpitch = Lpitch;
                 L.Lrows = Lrows;
-                L.min_w = L.min_h = 0xffffffffu;
+                L.mtx = su.mtx;
+                L.n_rows = su.n_rows;
+                L.live_list = live_list + su.live_offset;
+                L.live_count = c->d_counter + 8 + si;
+                L.super_index = (uint32_t)si;
                 const uint32_t t_limit = std::min(su.n_tiles, t0 + chunk_tiles);
                 uint32_t t1 = t0;
                 for (size_t i = 0; i < su.classes.size() && L.segs.n < (uint32_t)MAX_SEGS; i++) {
@@ -394,8 +486,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                     const uint32_t real = std::min(sc.n_templates, (e - cb) * 16) - (b - cb) * 16;
                     L.n_templates += real;
                     L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->n_pages;
-                    L.min_w = std::min(L.min_w, sc.n_w);
-                    L.min_h = std::min(L.min_h, sc.n_h);
                     t1 = e;
                 }
                 if (L.segs.n == 0) {
@@ -411,8 +501,16 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
         unsigned long long n_cand = 0;
+        uint32_t live_counts[40] = {0};
         FOCR_HIP(c, hipMemcpyAsync(&n_cand, (unsigned long long *)c->d_counter + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(live_counts, c->d_counter + 8, sizeof live_counts, hipMemcpyDeviceToHost, c->stream));
         FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        c->counters[3] = 0;
+        for (focr_launch_info_t &li : c->launches) {  // issued MACs follow the number of live M-tiles (known only now)
+            li.issued_macs *= live_counts[li.n_templates >> 24];
+            li.n_templates &= 0xffffff;
+            c->counters[3] += li.issued_macs;
+        }
         if (n_cand > c->cand_capacity) {
             if (n_cand > ((unsigned long long)1 << 33)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^33 candidates; scan fewer pages per call");
             want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;

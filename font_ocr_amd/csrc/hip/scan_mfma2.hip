@@ -26,8 +26,8 @@ size_t mfma2_bank_budget() { return V2_BANK_BUDGET; }
 
 template <int KSTEPS, int RPG, int MT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
-    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t mtx, uint32_t n_rows, uint32_t n_pages,
-    const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
+    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
+    const uint32_t *__restrict__ live_count, uint32_t n_pages, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const uint32_t *__restrict__ tglobal, uint32_t n_total, uint64_t *__restrict__ cand,
     unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -43,35 +43,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     uint64_t *wbuf = reinterpret_cast<uint64_t *>(smem + (size_t)bank_vec * 16) + w * WBUF;
     uint32_t wcount = 0;  // wave-uniform number of staged candidates
 
-    const uint32_t mt_per_page = mtx * n_rows;
-    const uint32_t total_mt = mt_per_page * n_pages;
+    const uint32_t total_mt = *live_count;  // live 16-window M-tiles of this pass (blank paper is skipped)
     const uint32_t n_items = (total_mt + MT - 1) / MT;
     const uint32_t n_waves = gridDim.x * NW;
 
     v4i afrag[MT][KSTEPS];
     for (uint32_t item = blockIdx.x * NW + w; item < n_items; item += n_waves) {
-        // (page, row, column) of the item's first M-tile; the others follow by increment-with-carry
-        uint32_t m0 = item * MT;
-        uint32_t page = m0 / mt_per_page, rem = m0 % mt_per_page, row = rem / mtx, col = rem % mtx;
+        // coordinates of the item's M-tiles (wave-uniform, scalar loads)
+        const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
         bool pv[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             pv[mt] = m0 + mt < total_mt;
-            px[mt] = 16 * col;
-            py[mt] = 1 + row;  // y = 0 is never searched (src/ncc.cpp:302)
-            pp[mt] = pv[mt] ? page : n_pages - 1;
-            if (++col == mtx) {
-                col = 0;
-                if (++row == n_rows) {
-                    row = 0;
-                    ++page;
-                }
-            }
+            const uint64_t e = live_list[pv[mt] ? m0 + mt : total_mt - 1];
+            px[mt] = 16 * (uint32_t)(e & 0xfff);
+            py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
+            pp[mt] = (uint32_t)(e >> 32);
         }
 
-        // C-in of the first segment: lane (r, g) owns output rows 4g..4g+3 (windows px+4g+i) of every M-tile.
-        // Unconditional loads (addresses are clamped) + arithmetic select: no branch, no wait between them.
         size_t loff[MT];
         v4i nl[MT];
 #pragma unroll
@@ -200,34 +190,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 
 template <int KSTEPS, int RPG, int MT, int NW>
 static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
-    const uint32_t mtx = (uint32_t)((c->r_w - L.min_w + 1 + 15) / 16);  // windows x in [0, r_w - min n_w]
-    const uint32_t n_rows = (uint32_t)(c->r_h - L.min_h);               // y in [1, r_h - min n_h]
     const uint32_t n_tiles16 = L.n_tiles16;
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
-    const uint64_t total_mt = (uint64_t)mtx * n_rows * c->n_pages;
+    const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->n_pages;  // upper bound; the live count is on the device
     const uint64_t n_items = (total_mt + MT - 1) / MT;
     unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
     auto kern = scan_mfma2_kernel<KSTEPS, RPG, MT, NW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset);
-    const uint64_t issued = n_items * MT * 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;
+    const uint64_t issued = 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;  // per live M-tile; scaled by the live count after the scan
     uint32_t dbg = 0;  // FOCR_MFMA_DBG: timing experiments only (bit0: skip candidate emission, bit1: reuse first A fragments)
     if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
-    c->launch_begin(name, L.n_templates, L.alg_macs, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, mtx,
-                       n_rows, (uint32_t)c->n_pages, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
+    c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
+                       L.live_list, L.live_count, (uint32_t)c->n_pages, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        (uint32_t)c->n_templates, c->d_cand, (unsigned long long *)c->d_counter + 1,
                        (unsigned long long)c->cand_capacity, dbg);
     c->launch_end();
-    c->counters[3] += issued;
 }
 
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     const uint32_t ks = L.ksteps, rpg = L.layout;
-    if ((uint64_t)((c->r_w - L.min_w + 16) / 16) * (c->r_h - L.min_h) * c->n_pages >= 0xffffffffull / 2)
-        return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
     int cfg = 3;  // FOCR_MFMA_CFG: 3 = 16 waves x MT 4 (default, measured best), 0 = 8 waves x MT 8, 1 = 12 waves x MT 6, 2 = 12 waves x MT 8
     if (const char *e = getenv("FOCR_MFMA_CFG")) cfg = atoi(e);
 #define CASE(K, R, M)                                                  \
