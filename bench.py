@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pages-per-gpu", type=int, default=128)
+    ap.add_argument("--config", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE configs[1] (608x720, 380 templates; the headline workload); c3 = configs[2] geometry "
+                         "(1200x1600 pages, --x-bits 2 --y-bits 2 = 1520 templates)")
     ap.add_argument("--mode", choices=["mfma", "direct"], default="mfma")
     ap.add_argument("--threshold", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,7 +90,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
-    bank = Bank.load(os.path.join(ROOT, "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
+    global R_W, R_H
+    bank_file = "bank_dejavu13_ascii95_x2.bin"
+    if args.config == "c3":
+        R_W, R_H = 1200, 1600
+        bank_file = "bank_dejavu13_ascii95_x2y2.bin"
+    bank = Bank.load(os.path.join(ROOT, "tests", "golden", bank_file))
     P = args.pages_per_gpu
     if args.noise:
         pages = np.random.default_rng(1234 + rank).integers(0, 256, (P, R_H, R_W), dtype=np.uint8)
@@ -177,8 +185,10 @@ def main():
         "dtype": "i8",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: 128 synthetic 608x720 pages per GPU, 95-glyph DejaVu Sans Mono 13px bank, "
-                        "--x-bits 2 --y-bits 0 (380 templates), threshold 0.8, cap 1024, + process_hits(0.95, 5)",
+            "workload": ("BASELINE configs[1]: 128 synthetic 608x720 pages per GPU, 95-glyph DejaVu Sans Mono 13px bank, "
+                         "--x-bits 2 --y-bits 0 (380 templates), threshold 0.8, cap 1024, + process_hits(0.95, 5)") if args.config == "c2"
+                        else (f"BASELINE configs[2] geometry: {P} synthetic 1200x1600 pages per GPU, 95-glyph bank, --x-bits 2 --y-bits 2 "
+                              "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
             "pages_per_gpu": P,
             "templates": len(bank),
             "scan_mode": args.mode,
@@ -201,7 +211,7 @@ def main():
             "peak": PEAK_I8_MFMA_TOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4),
-            "traffic": traffic_of(name),
+            "traffic": traffic_of(name) if args.config == "c2" and not args.noise else None,
             "avg_kernel_ms": round(k["ms"] / k["n"], 4),
             "algorithmic_macs_per_launch": k["alg"],
             "issued_macs_per_launch": k["issued"],
