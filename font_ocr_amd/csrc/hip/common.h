@@ -55,8 +55,19 @@ struct TemplateConst {
     uint32_t pad;
 };
 
-struct HitRecord {  // unordered device-side hit before ordering
-    uint64_t key;   // ((page * T + t) << 32) | (y << 16) | x
+// Device-side key of a candidate / hit: (page, y, x, t) packed with the minimal field widths of the batch, so that
+// one radix sort over bits [0, bits()) puts hits in process_hits order (page, y, x, template) with few passes.
+struct KeyFmt {
+    uint32_t bt, bx, by, bp;  // bits of template index, x, y, page
+    __host__ __device__ uint32_t bits() const { return bt + bx + by + bp; }
+    __host__ __device__ uint64_t pack(uint32_t page, uint32_t y, uint32_t x, uint32_t t) const {
+        return ((((uint64_t)page << by | y) << bx | x) << bt) | t;
+    }
+    __host__ __device__ uint32_t t(uint64_t k) const { return (uint32_t)(k & ((1ull << bt) - 1)); }
+    __host__ __device__ uint32_t x(uint64_t k) const { return (uint32_t)((k >> bt) & ((1ull << bx) - 1)); }
+    __host__ __device__ uint32_t y(uint64_t k) const { return (uint32_t)((k >> (bt + bx)) & ((1ull << by) - 1)); }
+    __host__ __device__ uint32_t page(uint64_t k) const { return (uint32_t)(k >> (bt + bx + by)); }
+    __host__ __device__ uint64_t line(uint64_t k) const { return k >> (bt + bx); }  // (page << by) | y
 };
 
 }  // namespace focr
@@ -93,6 +104,7 @@ struct focr_ctx {
     size_t stage_bytes = 0;
 
     // scan results
+    focr::KeyFmt fmt{};
     bool scanned = false;
     uint32_t cap = FOCR_MAX_MATCHES;
     size_t hit_capacity = 0;     // entries in d_hit_keys / d_hit_sims
@@ -112,8 +124,11 @@ struct focr_ctx {
     uint64_t *d_seg_start = nullptr;   // [n_pages*T] start in the sorted arrays
     uint64_t *d_seg_offset = nullptr;  // [n_pages*T + 1] CSR offsets of the capped lists
     size_t seg_alloc = 0;
-    focr_match_t *d_matches = nullptr;  // capped, ordered
-    uint64_t *d_match_keys = nullptr;   // parallel to d_matches: (page<<48 | y<<32 | x<<16 | t)
+    focr_match_t *d_matches = nullptr;  // capped, ordered by (page, template, y, x)
+    // all hits (before the cap) in process_hits order (page, y, x, t); d_keep[i] = survives its (page, template) cap
+    uint64_t *d_hkeys = nullptr;
+    float *d_hsims = nullptr;
+    size_t n_hits = 0;
     size_t matches_alloc = 0;
     size_t n_matches = 0;
 
@@ -125,6 +140,7 @@ struct focr_ctx {
         void release();
     };
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
+    DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
     bool lines_on_host = false;
     bool processed = false;
@@ -161,7 +177,7 @@ int fail(focr_ctx *ctx, int code, const std::string &msg);
 // launchers implemented in the .hip files
 int launch_scan_direct(focr_ctx *ctx, float threshold);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
-int order_hits(focr_ctx *ctx);
+int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
 int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
 
 // ---- device helpers: the reference's f64 epilogue, operation for operation ----

@@ -80,13 +80,13 @@ static void free_results(focr_ctx *c) {
     c->scan_pos.release();
     c->scan_live.release();
     c->scan_live_list.release();
+    for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep}) b->release();
     free_dev(c->d_L);
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);
     free_dev(c->d_seg_start);
     free_dev(c->d_seg_offset);
     free_dev(c->d_matches);
-    free_dev(c->d_match_keys);
     for (auto *b : {&c->post_keep, &c->post_choice, &c->post_owner, &c->post_packed, &c->post_scanned, &c->post_page_off,
                     &c->post_line_off, &c->post_chars})
         b->release();
@@ -406,6 +406,12 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     }
     c->counters[2] = macs * c->n_pages;
     c->counters[3] = 0;
+    auto nbits = [](size_t n) {
+        uint32_t b = 1;
+        while (((size_t)1 << b) < n) b++;
+        return b;
+    };
+    c->fmt = KeyFmt{nbits(c->n_templates), nbits(c->r_w), nbits(c->r_h), nbits(c->n_pages)};
     c->ordered = false;
     int rc = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
     if (rc) return rc;

@@ -15,8 +15,6 @@
 
 namespace focr {
 
-int sort_pairs_u64_f32(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, float *&vals, float *&vals_alt, size_t n,
-                       unsigned end_bit);
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 
 __device__ __forceinline__ int32_t total_key(float f) {  // f32::total_cmp as a signed-int order
@@ -24,73 +22,74 @@ __device__ __forceinline__ int32_t total_key(float f) {  // f32::total_cmp as a 
     return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1);
 }
 
-__global__ void mark_anchor_rows(const focr_match_t *__restrict__ m, const uint64_t *__restrict__ keys, size_t n,
-                                 float anchor, uint32_t r_h, uint8_t *__restrict__ keep) {
+// (1) keep_y: rows with a kept hit of similarity >= anchor_threshold
+__global__ void mark_anchor_rows(const uint64_t *__restrict__ hkeys, const float *__restrict__ hsims, const uint8_t *__restrict__ keep,
+                                 size_t n, KeyFmt fmt, float anchor, uint32_t r_h, uint8_t *__restrict__ keep_row) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (m[i].similarity >= anchor) keep[(size_t)(keys[i] >> 48) * r_h + m[i].y] = 1;
+    if (i >= n || !keep[i]) return;
+    if (hsims[i] >= anchor) keep_row[(size_t)fmt.page(hkeys[i]) * r_h + fmt.y(hkeys[i])] = 1;
 }
 
-__global__ void copy_sims(const focr_match_t *__restrict__ m, size_t n, float *__restrict__ sims) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sims[i] = m[i].similarity;
-}
-
-// One wave per (page, row): finds the row's extent in the sorted list by binary search, then walks it 64
-// elements at a time.  Groups are anchored on their first element (partition_by keeps `last` until a group
-// closes, src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave
-// operations: ballot for the group's extent inside the chunk, a 64-bit max-reduction for the winner
-// (key = total_cmp order of the similarity, then the element index, so the LAST maximum wins, :761-764).
+// One wave per (page, row): finds the row's extent in the (page, y, x, t)-sorted hit list by binary search, then
+// walks it 64 elements at a time.  Hits cut off by the per-call cap (keep[i] == 0) are not part of the reference's
+// all_hits and are transparent here.  Groups are anchored on their first element (partition_by keeps `last` until
+// a group closes, src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave
+// operations: ballot for the group's extent inside the chunk, a 64-bit max-reduction for the winner (key =
+// total_cmp order of the similarity, then the element index, so the LAST maximum wins, :761-764).
 // Outputs: choice[b + k] = winning element of the k-th group, owner[b + k] = b, packed[b] = 1<<32 | groups.
-__global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n,
-                                                  uint32_t r_h, uint32_t n_rows_total, int32_t overlap,
-                                                  const uint8_t *__restrict__ keep, uint32_t *__restrict__ choice,
-                                                  uint32_t *__restrict__ owner, uint64_t *__restrict__ packed) {
+__global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims,
+                                                  const uint8_t *__restrict__ keep, size_t n, KeyFmt fmt, uint32_t r_h,
+                                                  uint32_t n_rows_total, int32_t overlap, const uint8_t *__restrict__ keep_row,
+                                                  uint32_t *__restrict__ choice, uint32_t *__restrict__ owner,
+                                                  uint64_t *__restrict__ packed) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_rows_total) return;
-    if (!keep[wave]) return;  // keep is [page][y] with pitch r_h == wave index
-    const uint64_t line = ((uint64_t)(wave / r_h) << 16) | (uint64_t)(wave % r_h);  // (page, y)
+    if (!keep_row[wave]) return;  // keep_row is [page][y] with pitch r_h == wave index
+    const uint64_t line = ((uint64_t)(wave / r_h) << fmt.by) | (uint64_t)(wave % r_h);  // (page, y) as the key packs it
     uint64_t lo = 0, hi = n;
     while (lo < hi) {  // first element of the line
         uint64_t mid = (lo + hi) >> 1;
-        if ((keys[mid] >> 32) < line) lo = mid + 1;
+        if (fmt.line(keys[mid]) < line) lo = mid + 1;
         else hi = mid;
     }
     const uint64_t b = lo;
     hi = n;
     while (lo < hi) {  // one past its last element
         uint64_t mid = (lo + hi) >> 1;
-        if ((keys[mid] >> 32) <= line) lo = mid + 1;
+        if (fmt.line(keys[mid]) <= line) lo = mid + 1;
         else hi = mid;
     }
     const uint64_t e = lo;
     if (b == e) return;
 
     uint32_t groups = 0;
-    bool open = false;          // a group is open (carried across chunks)
-    int32_t anchor = 0;         // x of the open group's first element
-    uint64_t best = 0;          // (total_key ^ sign fix) << 32 | element index, of the open group
+    bool open = false;   // a group is open (carried across chunks)
+    int32_t anchor = 0;  // x of the open group's first element
+    uint64_t best = 0;   // (total_cmp order) << 32 | element index, of the open group
     for (uint64_t base = b; base < e; base += 64) {
         const uint64_t i = base + lane;
-        const bool valid = i < e;
-        const int32_t x = valid ? (int32_t)((keys[i] >> 16) & 0xffff) : 0x7fffffff;
+        const bool valid = i < e && keep[i];
+        const int32_t x = valid ? (int32_t)fmt.x(keys[i]) : 0x7fffffff;
         const uint32_t ord = valid ? ((uint32_t)total_key(sims[i]) ^ 0x80000000u) : 0u;  // unsigned order of total_cmp
         const uint64_t mine = ((uint64_t)ord << 32) | (uint32_t)(i - b);
-        const uint32_t n_valid = (uint32_t)(e - base < 64 ? e - base : 64);
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        const bool last_chunk = base + 64 >= e;
         uint32_t pos = 0;  // wave-uniform cursor inside the chunk
-        while (pos < n_valid) {
+        while (pos < 64) {
             if (!open) {
+                const uint64_t cand = vmask & (~0ull << pos);  // the next kept element opens a group
+                if (!cand) break;
+                pos = (uint32_t)__builtin_ctzll(cand);
                 anchor = __shfl(x, (int)pos);
                 best = 0;
                 open = true;
             }
-            // members of the open group inside this chunk: lanes [pos, stop)
-            const bool in = lane >= pos && valid && (x - anchor <= overlap) && (anchor - x <= overlap);
+            // kept members of the open group at/after pos; the first kept non-member closes it
+            const bool in = valid && lane >= pos && (x - anchor <= overlap) && (anchor - x <= overlap);
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
-            const uint64_t from = ~0ull << pos;
-            const uint64_t brk = ~inmask & from;  // first lane at/after pos that is not a member
+            const uint64_t brk = vmask & ~inmask & (~0ull << pos);
             const uint32_t stop = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
-            uint64_t v = (lane >= pos && lane < stop) ? mine : 0;
+            uint64_t v = (in && lane < stop) ? mine : 0;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const uint32_t vlo = __shfl_xor((uint32_t)v, o), vhi = __shfl_xor((uint32_t)(v >> 32), o);
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ k
                 v = other > v ? other : v;
             }
             if (v > best) best = v;
-            if (stop < n_valid || base + 64 >= e) {  // the group closes inside this chunk (or the line ends)
+            if (stop < 64) {  // the group closes inside this chunk
                 if (lane == 0) {
                     choice[b + groups] = (uint32_t)(b + (uint32_t)best);
                     owner[b + groups] = (uint32_t)b;
@@ -108,12 +107,20 @@ __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ k
             }
             pos = stop;
         }
+        if (last_chunk && open) {  // the line ends with a group still open
+            if (lane == 0) {
+                choice[b + groups] = (uint32_t)(b + (uint32_t)best);
+                owner[b + groups] = (uint32_t)b;
+            }
+            groups++;
+            open = false;
+        }
     }
     if (lane == 0) packed[b] = ((uint64_t)1 << 32) | groups;
 }
 
 // one thread per output character
-__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n,
+__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n, KeyFmt fmt,
                            const uint32_t *__restrict__ choice, const uint32_t *__restrict__ owner,
                            const uint64_t *__restrict__ scanned, const uint32_t *__restrict__ t_w,
                            const uint32_t *__restrict__ t_h, const uint32_t *__restrict__ t_letter,
@@ -127,10 +134,10 @@ __global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__res
     if (i == ls) line_char_off[sc >> 32] = sc & 0xffffffffu;
     const uint32_t e = choice[i];
     const uint64_t key = keys[e];
-    const uint32_t t = (uint32_t)(key & 0xffff);
+    const uint32_t t = fmt.t(key);
     focr_hit_t h;
-    h.x = (uint16_t)((key >> 16) & 0xffff);
-    h.y = (uint16_t)((key >> 32) & 0xffff);
+    h.x = (uint16_t)fmt.x(key);
+    h.y = (uint16_t)fmt.y(key);
     h.w = (uint16_t)t_w[t];
     h.h = (uint16_t)t_h[t];
     h.similarity = sims[e];
@@ -140,14 +147,14 @@ __global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__res
 }
 
 // page_line_off[p] = number of kept lines on pages < p
-__global__ void page_offsets(const uint64_t *__restrict__ keys, size_t n, const uint64_t *__restrict__ scanned,
+__global__ void page_offsets(const uint64_t *__restrict__ keys, size_t n, KeyFmt fmt, const uint64_t *__restrict__ scanned,
                              uint64_t total_lines, uint32_t n_pages, uint64_t *__restrict__ page_line_off) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_pages) return;
-    uint64_t lo = 0, hi = n, v = (uint64_t)p << 48;
+    uint64_t lo = 0, hi = n;
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < v) lo = mid + 1;
+        if (fmt.page(keys[mid]) < p) lo = mid + 1;
         else hi = mid;
     }
     page_line_off[p] = lo < n ? (scanned[lo] >> 32) : total_lines;
@@ -165,39 +172,34 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     FOCR_HIP(c, hipSetDevice(c->device));
     c->processed = false;
     c->lines_on_host = false;
-    const size_t n = c->n_matches, n_pages = c->n_pages;
+    const size_t n = c->n_hits, n_pages = c->n_pages;  // all hits in (page, y, x, t) order; d_keep marks the capped ones
     c->n_chars = c->n_lines = 0;
-    if (n == 0) {  // the reference panics on an empty hit list (src/ncc.rs:1040); we return zero lines
+    if (n == 0 || c->n_matches == 0) {  // the reference panics on an empty hit list (src/ncc.rs:1040); we return zero lines
         c->processed = true;
         c->ms[4] = 0.f;
         return FOCR_OK;
     }
-    if (n >= 0xffffffffull) return fail(c, FOCR_ERR_OVERFLOW, "focr_process_hits: more than 2^32 matches in one batch");
+    if (n >= 0xffffffffull) return fail(c, FOCR_ERR_OVERFLOW, "focr_process_hits: more than 2^32 hits in one batch");
     FOCR_HIP(c, hipEventRecord(c->ev[5], c->stream));
     // grow-only device scratch (no allocation in the steady state)
     const size_t n_rows_total = n_pages * c->r_h;
-    uint8_t *keep = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
+    uint8_t *keep_row = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
     uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, n * 4);
     uint32_t *owner = (uint32_t *)c->post_owner.ensure(c, n * 4);
     uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, n * 8);
     uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, n * 8);
     uint64_t *d_page_off = (uint64_t *)c->post_page_off.ensure(c, (n_pages + 1) * 8);
-    if (!keep || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
-    FOCR_HIP(c, hipMemsetAsync(keep, 0, n_rows_total, c->stream));
+    if (!keep_row || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    const uint8_t *keep = (const uint8_t *)c->ord_keep.p;
+    FOCR_HIP(c, hipMemsetAsync(keep_row, 0, n_rows_total, c->stream));
     FOCR_HIP(c, hipMemsetAsync(owner, 0xff, n * 4, c->stream));
     FOCR_HIP(c, hipMemsetAsync(packed, 0, n * 8, c->stream));
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_matches, c->d_match_keys, n,
-                       anchor_threshold, (uint32_t)c->r_h, keep);
-    // sort (key = page|y|x|t, value = similarity); the hit buffers of the scan are reused as scratch
-    hipLaunchKernelGGL(copy_sims, dim3(nb), dim3(256), 0, c->stream, c->d_matches, n, c->d_hit_sims);
-    FOCR_HIP(c, hipMemcpyAsync(c->d_hit_keys, c->d_match_keys, n * 8, hipMemcpyDeviceToDevice, c->stream));
-    unsigned page_bits = 1;
-    while (((size_t)1 << page_bits) < n_pages) page_bits++;
-    int rc = sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims, c->d_hit_sims_alt, n, 48 + page_bits);
-    if (rc) return rc;
-    hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hit_keys,
-                       c->d_hit_sims, n, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep, choice, owner, packed);
+    hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, n, c->fmt, anchor_threshold,
+                       (uint32_t)c->r_h, keep_row);
+    hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
+                       keep, n, c->fmt, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep_row, choice, owner, packed);
+    int rc;
     if ((rc = exclusive_scan_u64(c, packed, scanned, n))) return rc;
     uint64_t last_scan = 0, last_packed = 0;
     FOCR_HIP(c, hipMemcpyAsync(&last_scan, scanned + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
@@ -209,9 +211,9 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     uint64_t *d_line_off = (uint64_t *)c->post_line_off.ensure(c, (c->n_lines + 1) * 8);
     focr_hit_t *d_chars = (focr_hit_t *)c->post_chars.ensure(c, (c->n_chars ? c->n_chars : 1) * sizeof(focr_hit_t));
     if (!d_line_off || !d_chars) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
-    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hit_keys, c->d_hit_sims, n, choice, owner, scanned,
+    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, n, c->fmt, choice, owner, scanned,
                        c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
-    hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_hit_keys, n,
+    hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, n, c->fmt,
                        scanned, (uint64_t)c->n_lines, (uint32_t)n_pages, d_page_off);
     FOCR_HIP(c, hipGetLastError());
     FOCR_HIP(c, hipEventRecord(c->ev[6], c->stream));
@@ -227,7 +229,7 @@ static int fetch_lines(focr_ctx *c) {
     c->h_page_line_off.assign(c->n_pages + 1, 0);
     c->h_line_char_off.assign(c->n_lines + 1, 0);
     c->h_chars.resize(c->n_chars);
-    if (c->n_matches) {
+    if (c->n_matches && (c->n_lines || c->n_chars)) {
         FOCR_HIP(c, hipSetDevice(c->device));
         if (c->n_lines)
             FOCR_HIP(c, hipMemcpyAsync(c->h_line_char_off.data(), c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
                                                           uint32_t rows_alloc, uint32_t r_w, uint32_t r_h, uint32_t n_w,
                                                           uint32_t n_h, const uint32_t *__restrict__ bank,
                                                           const TemplateConst *__restrict__ tc, uint32_t n_class,
-                                                          uint32_t n_total, double thr_d, uint64_t *__restrict__ hit_keys,
+                                                          KeyFmt fmt, double thr_d, uint64_t *__restrict__ hit_keys,
                                                           float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
                                                           unsigned long long capacity) {
     constexpr int LROWS = DTY + MAXH - 1;
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
         }
     }
     const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(n_w * n_h));
-    const uint64_t key_lo = ((uint64_t)y << 16) | (uint64_t)x;
 
     for (uint32_t t = 0; t < n_class; t++) {
         const uint32_t *tp = bank + (size_t)t * (MAXH * NDW);
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
         if (valid && ncc_emits(sim, thr_d)) {
             unsigned long long idx = atomicAdd(counter, 1ull);
             if (idx < capacity) {
-                hit_keys[idx] = ((uint64_t)(page * n_total + tc[t].index) << 32) | key_lo;
+                hit_keys[idx] = fmt.pack(page, y, x, tc[t].index);
                 hit_sims[idx] = (float)sim;
             }
         }
@@ -95,7 +94,7 @@ static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d)
     hipLaunchKernelGGL((scan_direct_kernel<NDW, MAXH>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
                        c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates,
-                       (uint32_t)c->n_templates, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
+                       c->fmt, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
                        (unsigned long long)c->hit_capacity);
     c->launch_end();
 }

@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void compact_live_tiles(const uint8_t *__restr
 // 3. exact verify: the reference arithmetic on every candidate
 typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
 
-// Candidates arrive sorted by key = (page*T + t, y, x): neighbouring lanes verify neighbouring windows of the same
-// template (cache-friendly), and the survivors are already in the reference's emission order, so no atomics and no
-// second sort: flag[i] / sim[i] are written in place and order.hip compacts them.
+// Candidates arrive sorted by the packed key (page, y, x, t): neighbouring lanes verify the same or neighbouring
+// windows (cache-friendly), and the survivors stay in process_hits order, so no atomics: flag[i] / sim[i] are
+// written in place and order.hip compacts them and derives the per-call lists.
 __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, unsigned long long n_cand,
                                                      const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
-                                                     uint32_t n_total, const uint32_t *__restrict__ order_of,
+                                                     KeyFmt fmt, const uint32_t *__restrict__ order_of,
                                                      const TemplateConst *__restrict__ tc, const v4i *__restrict__ needles16,
                                                      const uint32_t *__restrict__ needle16_row, double thr_d,
                                                      float *__restrict__ sims, uint64_t *__restrict__ flags) {
@@ -188,8 +188,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
         return;
     }
     const uint64_t key = cand[i];
-    const uint32_t seg = (uint32_t)(key >> 32), page = seg / n_total, t = seg % n_total;
-    const uint32_t x = (uint32_t)(key & 0xffff), y = (uint32_t)((key >> 16) & 0xffff);
+    const uint32_t page = fmt.page(key), t = fmt.t(key), x = fmt.x(key), y = fmt.y(key);
     const uint32_t ci = order_of[t];
     const TemplateConst c = tc[ci];
     const v4i *nd = needles16 + needle16_row[ci];  // n_h rows of 16 bytes, zero padded past n_w
@@ -530,11 +529,9 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (hipMalloc(&c->d_cand_alt, c->cand_capacity * 8) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
             c->cand_alt_capacity = c->cand_capacity;
         }
-        unsigned seg_bits = 1;
-        while (((uint64_t)1 << seg_bits) < (uint64_t)c->n_pages * c->n_templates) seg_bits++;
-        if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, (size_t)n_cand, 32 + seg_bits))) return rc;
+        if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, (size_t)n_cand, c->fmt.bits()))) return rc;
         hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((n_cand + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand,
-                           c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, (uint32_t)c->n_templates, c->d_order_of,
+                           c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of,
                            c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_sims,
                            flags);
         FOCR_HIP(c, hipGetLastError());

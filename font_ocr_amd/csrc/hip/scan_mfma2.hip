@@ -28,7 +28,7 @@ template <int KSTEPS, int RPG, int MT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t n_pages, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
-    const uint32_t *__restrict__ tglobal, uint32_t n_total, uint64_t *__restrict__ cand,
+    const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
     unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
@@ -173,9 +173,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                                 // from hoisting 8 M-tiles' worth of 64-bit keys out of the N-tile loop and spilling them)
                                 uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
                                 asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));
-                                if (ok)
-                                    wbuf[wcount + pos] = ((uint64_t)(pg * n_total + tg) << 32) | ((uint64_t)yy << 16) |
-                                                         (uint64_t)(xx + 4 * g + i);
+                                if (ok) wbuf[wcount + pos] = fmt.pack(pg, yy, xx + 4 * g + i, tg);
                                 wcount += cnt;
                             }
                         }
@@ -206,7 +204,7 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->n_pages, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
-                       (uint32_t)c->n_templates, c->d_cand, (unsigned long long *)c->d_counter + 1,
+                       c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
                        (unsigned long long)c->cand_capacity, dbg);
     c->launch_end();
 }
