@@ -25,9 +25,9 @@ def gather_chars(mine, rank, world, device=None):
 
     dev = mine.device if device is None else device
     n = torch.tensor([mine.numel()], device=dev, dtype=torch.int64)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    all_n = torch.empty(world, device=dev, dtype=torch.int64)
+    dist.all_gather_into_tensor(all_n, n)
+    sizes = all_n.tolist()  # one device->host read for all ranks' sizes
     mx = max(max(sizes), 1)
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[: mine.numel()] = mine
