@@ -28,7 +28,6 @@ struct SizeClass {
     uint32_t n_tiles16;       // ceil(n_templates / 16)
     uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
     uint32_t tg_offset;       // entry offset of the class's template ids in d_tglobal (16 per N-tile, ~0 = padding/dead)
-    float kappa;              // prefilter slope: flag iff G > kappa * norm_p (see scan_mfma.hip)
 };
 
 // Classes whose A fragments are identical (same K layout, same number of K-steps) are scanned in one kernel

@@ -324,7 +324,6 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
                     qbank[sc.q_offset + ((size_t)(nt * ksteps + ks) * 64 + g * 16 + nn) * 16 + byte] = (int8_t)bq[j * sc.n_w + x];
                 }
         }
-        sc.kappa = 0.f;  // per-scan (depends on the threshold); keep the two ingredients
         c->mfma_c_scale.push_back(c_scale);
         c->mfma_e_max.push_back(e_max);
     }
