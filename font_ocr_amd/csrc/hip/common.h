@@ -103,6 +103,7 @@ struct focr_ctx {
     size_t stage_bytes = 0;
 
     // scan results
+    size_t sub_p0 = 0, sub_np = 0;  // page range the scan pipeline is currently working on (normally the whole batch)
     focr::KeyFmt fmt{};
     bool scanned = false;
     uint32_t cap = FOCR_MAX_MATCHES;
@@ -136,10 +137,12 @@ struct focr_ctx {
         void *p = nullptr;
         size_t bytes = 0;
         void *ensure(focr_ctx *c, size_t want);
+        void *ensure_keep(focr_ctx *c, size_t want, size_t keep_bytes);
         void release();
     };
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
+    DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch
     DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
     bool lines_on_host = false;
     bool processed = false;
@@ -176,6 +179,7 @@ int fail(focr_ctx *ctx, int code, const std::string &msg);
 // launchers implemented in the .hip files
 int launch_scan_direct(focr_ctx *ctx, float threshold);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
+int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
 int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
 

@@ -39,6 +39,26 @@ __global__ void debug_rnorm_kernel(const uint32_t *s, const uint64_t *s2, const 
     if (i < cnt) out[i] = window_rnorm(s[i], s2[i], (double)n[i]);
 }
 
+// split-batch mode: keep only the hits that survive their call's cap, appended in order
+__global__ void append_kept_hits(const uint64_t *__restrict__ hkeys, const float *__restrict__ hsims, const uint8_t *__restrict__ keep,
+                                 const uint64_t *__restrict__ pos, size_t n, uint64_t *__restrict__ out_keys,
+                                 float *__restrict__ out_sims) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    out_keys[pos[i]] = hkeys[i];
+    out_sims[pos[i]] = hsims[i];
+}
+
+__global__ void widen_u8_to_u64(const uint8_t *__restrict__ in, size_t n, uint64_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+__global__ void widen_u32_to_u64(const uint32_t *__restrict__ in, size_t n, uint64_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) out[i] = i < n ? in[i] : 0;
+}
+
 template <typename T>
 static void free_dev(T *&p) {
     if (p) (void)hipFree(p);
@@ -80,7 +100,9 @@ static void free_results(focr_ctx *c) {
     c->scan_pos.release();
     c->scan_live.release();
     c->scan_live_list.release();
-    for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep}) b->release();
+    for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep, &c->acc_matches, &c->acc_seg_count,
+                    &c->acc_hkeys, &c->acc_hsims})
+        b->release();
     free_dev(c->d_L);
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);
@@ -109,6 +131,20 @@ void *focr_ctx::DevBuf::ensure(focr_ctx *c, size_t want) {
         p = nullptr;
         return nullptr;
     }
+    bytes = grow;
+    return p;
+}
+
+// grow while preserving the first `keep_bytes` bytes
+void *focr_ctx::DevBuf::ensure_keep(focr_ctx *c, size_t want, size_t keep_bytes) {
+    if (want <= bytes && p) return p;
+    (void)hipStreamSynchronize(c->stream);
+    void *q = nullptr;
+    size_t grow = want + want / 2 + 256;
+    if (hipMalloc(&q, grow) != hipSuccess) return nullptr;
+    if (p && keep_bytes) (void)hipMemcpy(q, p, keep_bytes, hipMemcpyDeviceToDevice);
+    if (p) (void)hipFree(p);
+    p = q;
     bytes = grow;
     return p;
 }
@@ -386,6 +422,85 @@ int focr_pages_upload_device(focr_ctx_t *c, size_t first, size_t count, const vo
     return ingest(c, (const uint8_t *)d_luma, first, count, invert);
 }
 
+}  // extern "C"
+
+template <typename Run>
+static int scan_split(focr_ctx *c, Run &run) {
+    const size_t T = c->n_templates, n_seg_all = c->n_pages * T;
+    size_t match_total = 0, hit_total = 0, raw_total = 0, cand_total = 0;
+    float ms_acc[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t issued = 0;
+    uint32_t *acc_cnt = (uint32_t *)c->acc_seg_count.ensure(c, (n_seg_all + 1) * 4);
+    if (!acc_cnt) return fail(c, FOCR_ERR_NOMEM, "focr_scan: hipMalloc failed");
+    size_t np = std::max<size_t>(1, c->n_pages / 2);
+    for (size_t p0 = 0; p0 < c->n_pages;) {
+        np = std::min(np, c->n_pages - p0);
+        int rc = run(p0, np);
+        if ((rc == FOCR_ERR_OVERFLOW || rc == FOCR_ERR_NOMEM) && np > 1) {
+            np = (np + 1) / 2;  // still too much: halve and retry the same pages
+            continue;
+        }
+        if (rc) return rc;
+        // append: matches, per-call counts, kept hits
+        const size_t nm = c->n_matches, nh = c->n_hits;
+        focr_match_t *am = (focr_match_t *)c->acc_matches.ensure_keep(c, (match_total + nm + 1) * sizeof(focr_match_t), match_total * sizeof(focr_match_t));
+        uint64_t *ak = (uint64_t *)c->acc_hkeys.ensure_keep(c, (hit_total + nm + 1) * 8, hit_total * 8);
+        float *as = (float *)c->acc_hsims.ensure_keep(c, (hit_total + nm + 1) * 4, hit_total * 4);
+        if (!am || !ak || !as) return fail(c, FOCR_ERR_NOMEM, "focr_scan: hipMalloc failed");
+        if (nm) FOCR_HIP(c, hipMemcpyAsync(am + match_total, c->d_matches, nm * sizeof(focr_match_t), hipMemcpyDeviceToDevice, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(acc_cnt + p0 * T, c->d_seg_count, np * T * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (nh) {
+            uint64_t *f64 = (uint64_t *)c->scan_flags.ensure(c, (nh + 1) * 8), *pos = (uint64_t *)c->scan_pos.ensure(c, (nh + 1) * 8);
+            if (!f64 || !pos) return fail(c, FOCR_ERR_NOMEM, "focr_scan: hipMalloc failed");
+            const unsigned nb = (unsigned)((nh + 255) / 256);
+            hipLaunchKernelGGL(widen_u8_to_u64, dim3(nb), dim3(256), 0, c->stream, (const uint8_t *)c->ord_keep.p, nh, f64);
+            if ((rc = exclusive_scan_u64(c, f64, pos, nh))) return rc;
+            hipLaunchKernelGGL(append_kept_hits, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, (const uint8_t *)c->ord_keep.p,
+                               pos, nh, ak + hit_total, as + hit_total);
+            FOCR_HIP(c, hipGetLastError());
+        }
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        match_total += nm;
+        hit_total += nm;  // kept hits == matches
+        raw_total += c->n_hits_raw;
+        cand_total += c->n_cand;
+        issued += c->counters[3];
+        for (int i = 0; i < 6; i++) ms_acc[i] += c->ms[i];
+        p0 += np;
+    }
+    // install the accumulated results as the scan's results
+    {
+        uint64_t *count64 = c->d_seg_start + (n_seg_all + 1);  // seg arrays were sized for the whole batch by the sub-runs
+        hipLaunchKernelGGL(widen_u32_to_u64, dim3((unsigned)((n_seg_all + 256) / 256)), dim3(256), 0, c->stream, acc_cnt, n_seg_all, count64);
+        int rc = exclusive_scan_u64(c, count64, c->d_seg_offset, n_seg_all + 1);
+        if (rc) return rc;
+        FOCR_HIP(c, hipMemcpyAsync(c->d_seg_count, acc_cnt, n_seg_all * 4, hipMemcpyDeviceToDevice, c->stream));
+        uint8_t *keep = (uint8_t *)c->ord_keep.ensure(c, hit_total + 1);
+        if (!keep) return fail(c, FOCR_ERR_NOMEM, "focr_scan: hipMalloc failed");
+        FOCR_HIP(c, hipMemsetAsync(keep, 1, hit_total + 1, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        std::swap(c->d_matches, *(focr_match_t **)&c->acc_matches.p);  // hand the accumulated list over (capacities swap too)
+        size_t acc_cap = c->acc_matches.bytes / sizeof(focr_match_t);
+        c->acc_matches.bytes = c->matches_alloc * sizeof(focr_match_t);
+        c->matches_alloc = acc_cap;
+        c->d_hkeys = (uint64_t *)c->acc_hkeys.p;
+        c->d_hsims = (float *)c->acc_hsims.p;
+    }
+    c->sub_p0 = 0;
+    c->sub_np = c->n_pages;
+    c->n_matches = match_total;
+    c->n_hits = hit_total;
+    c->n_hits_raw = raw_total;
+    c->n_cand = cand_total;
+    c->counters[0] = cand_total;
+    c->counters[1] = raw_total;
+    c->counters[3] = issued;
+    for (int i = 0; i < 6; i++) c->ms[i] = ms_acc[i];
+    return FOCR_OK;
+}
+
+extern "C" {
+
 int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     if (!c) return FOCR_ERR_INVALID;
     if (!c->n_templates) return fail(c, FOCR_ERR_STATE, "focr_scan: no bank uploaded");
@@ -412,12 +527,24 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         return b;
     };
     c->fmt = KeyFmt{nbits(c->n_templates), nbits(c->r_w), nbits(c->r_h), nbits(c->n_pages)};
-    c->ordered = false;
-    int rc = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
-    if (rc) return rc;
-    if (!c->ordered) {
-        rc = order_hits(c);
+    auto run = [&](size_t p0, size_t np) -> int {  // the whole pipeline on pages [p0, p0 + np)
+        c->sub_p0 = p0;
+        c->sub_np = np;
+        c->ordered = false;
+        int r = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
+        if (r) return r;
+        return c->ordered ? FOCR_OK : order_hits(c);
+    };
+    // FOCR_FORCE_SPLIT=1 (tests): take the split-batch path without waiting for an overflow
+    const bool force_split = getenv("FOCR_FORCE_SPLIT") && atoi(getenv("FOCR_FORCE_SPLIT")) != 0;
+    int rc = force_split ? FOCR_ERR_OVERFLOW : run(0, c->n_pages);
+    if (rc == FOCR_ERR_OVERFLOW || rc == FOCR_ERR_NOMEM) {
+        // Too many candidates for one pass (very low thresholds): scan the batch in page sub-ranges and append the
+        // results.  Only hits that survive the per-call cap are kept, so the totals stay bounded by pages x T x cap.
+        rc = scan_split(c, run);
         if (rc) return rc;
+    } else if (rc) {
+        return rc;
     }
     c->scanned = true;
     return FOCR_OK;

@@ -93,11 +93,11 @@ __global__ void compact_hits(const uint64_t *__restrict__ keys, const float *__r
 }
 
 __global__ void build_segment_keys(const uint64_t *__restrict__ hkeys, uint64_t n, KeyFmt fmt, uint32_t n_templates,
-                                   uint64_t *__restrict__ k2, float *__restrict__ v) {
+                                   uint32_t page_base, uint64_t *__restrict__ k2, float *__restrict__ v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = hkeys[i];
-    k2[i] = (uint64_t)fmt.page(k) * n_templates + fmt.t(k);
+    k2[i] = (uint64_t)(fmt.page(k) - page_base) * n_templates + fmt.t(k);
     v[i] = __uint_as_float((uint32_t)i);  // the hit's index rides along as the sort value
 }
 
@@ -171,9 +171,9 @@ static int ensure_matches(focr_ctx *c, size_t want) {
 // hits already sorted by the packed (page, y, x, t) key -> per-call lists + keep flags; ends with the read-back of
 // the result sizes.
 static int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, size_t n) {
-    const size_t n_seg = c->n_pages * c->n_templates;
+    const size_t n_seg = c->sub_np * c->n_templates;  // (page, template) calls of the pages being processed
     int rc;
-    if ((rc = ensure_seg_arrays(c, n_seg))) return rc;
+    if ((rc = ensure_seg_arrays(c, c->n_pages * c->n_templates))) return rc;
     if ((rc = ensure_matches(c, n))) return rc;  // matches <= hits
     uint64_t *k2 = (uint64_t *)c->ord_k2.ensure(c, (n + 1) * 8), *k2_alt = (uint64_t *)c->ord_k2_alt.ensure(c, (n + 1) * 8);
     float *v = (float *)c->ord_v.ensure(c, (n + 1) * 4), *v_alt = (float *)c->ord_v_alt.ensure(c, (n + 1) * 4);
@@ -185,9 +185,10 @@ static int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, size_t 
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (n) {
         hipLaunchKernelGGL(build_segment_keys, dim3(nb), dim3(256), 0, c->stream, hkeys, (uint64_t)n, c->fmt, (uint32_t)c->n_templates,
-                           k2, v);
+                           (uint32_t)c->sub_p0, k2, v);
         FOCR_HIP(c, hipGetLastError());
         if ((rc = sort_pairs_u64_f32(c, k2, k2_alt, v, v_alt, n, c->fmt.bp + c->fmt.bt))) return rc;  // LSD radix sort: stable
+        // (the sort may have swapped k2/v with their alternates; they are local pointers, the DevBufs keep ownership)
     }
     hipLaunchKernelGGL(segment_bounds, dim3((unsigned)((n_seg + 1 + 255) / 256)), dim3(256), 0, c->stream, k2, (uint64_t)n,
                        (uint32_t)n_seg, c->cap, c->d_seg_start, c->d_seg_count, count64);

@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
                                                           const TemplateConst *__restrict__ tc, uint32_t n_class,
                                                           KeyFmt fmt, double thr_d, uint64_t *__restrict__ hit_keys,
                                                           float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
-                                                          unsigned long long capacity) {
+                                                          unsigned long long capacity, uint32_t page_base) {
     constexpr int LROWS = DTY + MAXH - 1;
     __shared__ uint32_t tile[LROWS][DLDW];
-    const uint32_t page = blockIdx.z;
+    const uint32_t page = page_base + blockIdx.z;
     const uint32_t x0 = blockIdx.x * DTX;      // byte column of LDS column 0 (dword aligned)
     const uint32_t y0 = 1 + blockIdx.y * DTY;  // y = 0 is never searched (src/ncc.cpp:302)
     const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
 template <int NDW, int MAXH>
 static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d) {
     dim3 grid((unsigned)((c->r_w - sc.n_w + DTX - 1) / DTX), (unsigned)((c->r_h - sc.n_h + DTY - 1) / DTY),
-              (unsigned)c->n_pages);
-    const uint64_t win = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * c->n_pages;
+              (unsigned)c->sub_np);
+    const uint64_t win = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * c->sub_np;
     char name[64];
     snprintf(name, sizeof name, "scan_direct_kernel<%d,%d>", NDW, MAXH);
     c->launch_begin(name, sc.n_templates, win * sc.n_w * sc.n_h * sc.n_templates, win * NDW * 4 * MAXH * sc.n_templates);
@@ -95,7 +95,7 @@ static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d)
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
                        c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates,
                        c->fmt, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
-                       (unsigned long long)c->hit_capacity);
+                       (unsigned long long)c->hit_capacity, (uint32_t)c->sub_p0);
     c->launch_end();
 }
 
@@ -117,7 +117,7 @@ int ensure_hit_capacity(focr_ctx *c, size_t want) {
 
 int launch_scan_direct(focr_ctx *c, float threshold) {
     const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
-    int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->n_pages * 65536)));
+    int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
     for (int attempt = 0; attempt < 3; attempt++) {
         c->launches_reset();
@@ -139,7 +139,7 @@ int launch_scan_direct(focr_ctx *c, float threshold) {
                 default: return fail(c, FOCR_ERR_INVALID, "scan_direct: unsupported size class");
             }
             FOCR_HIP(c, hipGetLastError());
-            c->counters[3] += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.ndw * 4 * sc.maxh * sc.n_templates * c->n_pages;
+            c->counters[3] += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.ndw * 4 * sc.maxh * sc.n_templates * c->sub_np;
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));

@@ -353,13 +353,13 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
 template <int NDW>
 static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t *negL, uint32_t Lpitch, uint32_t Lrows,
                          uint8_t *live, uint32_t mtx, uint32_t n_rows) {
-    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->n_pages);
+    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
     // kq = kappa / sqrt(n), rounded toward -inf so that the f32 product never overshoots the true threshold
     const double kq_d = kappa / std::sqrt((double)(sc.n_w * sc.n_h));
     float kq = (float)kq_d;
     if ((double)kq > kq_d) kq = std::nextafterf(kq, -INFINITY);
     kq = std::nextafterf(kq, -INFINITY);
-    hipLaunchKernelGGL((stats_kernel<NDW>), grid, dim3(256), 0, c->stream, c->d_pages, (uint32_t)c->pitch,
+    hipLaunchKernelGGL((stats_kernel<NDW>), grid, dim3(256), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
                        n_rows);
 }
@@ -377,9 +377,9 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         if (hipMalloc(&c->d_L, L_bytes) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(negL) failed");
         c->L_bytes = L_bytes;
     }
-    int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->n_pages * 65536)));
+    int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
-    size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->n_pages * 131072));
+    size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->sub_np * 131072));
     hipDeviceProp_t prop;
     FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
 
@@ -413,7 +413,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (su.min_w == 0xffffffffu) continue;  // nothing searchable
             su.mtx = (uint32_t)((c->r_w - su.min_w + 1 + 15) / 16);  // windows x in [0, r_w - min n_w]
             su.n_rows = (uint32_t)(c->r_h - su.min_h);               // y in [1, r_h - min n_h]
-            const uint64_t nt = (uint64_t)su.mtx * su.n_rows * c->n_pages;
+            const uint64_t nt = (uint64_t)su.mtx * su.n_rows * c->sub_np;
             if (nt >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
             tiles_total += (size_t)nt;
         }
@@ -440,7 +440,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 }
                 FOCR_HIP(c, hipGetLastError());
             }
-            const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->n_pages);
+            const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->sub_np);
             hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
                                su.n_rows, (dbg & 8) ? 0u : 1u, live_list + su.live_offset, c->d_counter + 8 + si);
             FOCR_HIP(c, hipGetLastError());
@@ -483,7 +483,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                     sg.tile_end = e - t0;
                     const uint32_t real = std::min(sc.n_templates, (e - cb) * 16) - (b - cb) * 16;
                     L.n_templates += real;
-                    L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->n_pages;
+                    L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->sub_np;
                     t1 = e;
                 }
                 if (L.segs.n == 0) {
@@ -510,7 +510,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             c->counters[3] += li.issued_macs;
         }
         if (n_cand > c->cand_capacity) {
-            if (n_cand > ((unsigned long long)1 << 33)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^33 candidates; scan fewer pages per call");
+            if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
             want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;
             continue;
         }

@@ -27,7 +27,7 @@ size_t mfma2_bank_budget() { return V2_BANK_BUDGET; }
 template <int KSTEPS, int RPG, int MT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
-    const uint32_t *__restrict__ live_count, uint32_t n_pages, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
+    const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
     unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                                 // from hoisting 8 M-tiles' worth of 64-bit keys out of the N-tile loop and spilling them)
                                 uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
                                 asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));
-                                if (ok) wbuf[wcount + pos] = fmt.pack(pg, yy, xx + 4 * g + i, tg);
+                                if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pg, yy, xx + 4 * g + i, tg);
                                 wcount += cnt;
                             }
                         }
@@ -190,7 +190,7 @@ template <int KSTEPS, int RPG, int MT, int NW>
 static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     const uint32_t n_tiles16 = L.n_tiles16;
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
-    const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->n_pages;  // upper bound; the live count is on the device
+    const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;  // upper bound; the live count is on the device
     const uint64_t n_items = (total_mt + MT - 1) / MT;
     unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
     auto kern = scan_mfma2_kernel<KSTEPS, RPG, MT, NW>;
@@ -202,8 +202,8 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
-                       L.live_list, L.live_count, (uint32_t)c->n_pages, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
+                       L.live_list, L.live_count, (uint32_t)c->sub_p0, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
                        (unsigned long long)c->cand_capacity, dbg);
     c->launch_end();

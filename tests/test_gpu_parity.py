@@ -290,3 +290,32 @@ def test_full_page_low_threshold_hits_the_cap(scanner, bank_x2, mode):
     _assert_same(_csr_to_lists(offsets, m, 1, len(bank)), want, "cap")
     assert (counts == 1024).sum() >= 3, counts.max()  # the cap really was exercised
     assert scanner.counters()["raw_hits"] > int(counts.sum())  # ... and some hits were cut off
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_split_batch_fallback_equals_single_pass(scanner, bank_x2, mode, monkeypatch):
+    """The candidate-overflow fallback (scan the batch in page sub-ranges, append) must give the same lists and
+    the same process_hits output as the single pass; forced here through FOCR_FORCE_SPLIT."""
+    bank = bank_x2.subset(list(range(33, 70)) + list(range(95 + 33, 95 + 70)))
+    pages = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 600 + p, 256, 110) for p in range(5)])
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    out = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("FOCR_FORCE_SPLIT", split)
+        for thr, cap in ((0.8, 1024), (0.2, 50)):
+            scanner.scan(thr, cap, mode)
+            counts = scanner.counts().copy()
+            offsets, m = scanner.matches()
+            scanner.process_hits(0.9, 5)
+            chars = scanner.lines_flat().copy()
+            out[(split, thr)] = (counts, offsets.copy(), m.copy(), chars)
+    monkeypatch.setenv("FOCR_FORCE_SPLIT", "0")
+    for thr in (0.8, 0.2):
+        a, b = out[("0", thr)], out[("1", thr)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[2].tobytes() == b[2].tobytes()
+        assert a[3].tobytes() == b[3].tobytes()
+    want = _oracle_lists(pages, bank, 0.2, 50)
+    _assert_same(_csr_to_lists(out[("1", 0.2)][1], out[("1", 0.2)][2], 5, len(bank)), want, "split thr=0.2 cap=50")
+    assert (out[("1", 0.2)][0] == 50).any()
