@@ -9,12 +9,14 @@
 //     Rust scan (src/ncc.rs:406-483) — both are "the other implementation" used for A/B checks;
 //   * a page without any hit prints nothing (the reference panics in partition_by, src/ncc.rs:1040).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -263,10 +265,24 @@ int main(int argc, char **argv) {
     };
     std::vector<Page> pages(args.img.size());
     std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
-    for (size_t i = 0; i < args.img.size(); i++) {
-        if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, err, sizeof err) != 0)
-            die(std::string("cannot open image: ") + err);  // image::open(..).unwrap(), src/ncc.rs:575
-        groups[{pages[i].w, pages[i].h}].push_back(i);
+    {  // decode on all host cores (the reference decodes inside its per-page rayon tasks, src/ncc.rs:839-847, 575)
+        std::atomic<size_t> next{0};
+        std::vector<std::string> errs(args.img.size());
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < args.img.size();) {
+                char e[256] = {0};
+                if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, e, sizeof e) != 0) errs[i] = e[0] ? e : "?";
+            }
+        };
+        unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)args.img.size()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        for (size_t i = 0; i < args.img.size(); i++) {
+            if (!errs[i].empty()) die("cannot open image: " + errs[i]);  // image::open(..).unwrap(), src/ncc.rs:575
+            groups[{pages[i].w, pages[i].h}].push_back(i);
+        }
     }
 
     focr_ctx_t *ctx = nullptr;
