@@ -507,7 +507,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_scan: no pages resident");
     if (cap == 0) return fail(c, FOCR_ERR_INVALID, "focr_scan: cap must be >= 1 (src/ncc.cpp:43-46)");
     if (mode != FOCR_SCAN_MFMA && mode != FOCR_SCAN_DIRECT) return fail(c, FOCR_ERR_INVALID, "focr_scan: bad mode");
-    if (std::isnan(threshold)) return fail(c, FOCR_ERR_INVALID, "focr_scan: threshold is NaN");
+    if (std::isnan(threshold)) threshold = INFINITY;  // `sim > NaN` is never true in the reference (src/ncc.cpp:362-366): no hits
     FOCR_HIP(c, hipSetDevice(c->device));
     c->cap = cap;
     c->scanned = c->processed = false;

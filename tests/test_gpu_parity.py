@@ -319,3 +319,21 @@ def test_split_batch_fallback_equals_single_pass(scanner, bank_x2, mode, monkeyp
     want = _oracle_lists(pages, bank, 0.2, 50)
     _assert_same(_csr_to_lists(out[("1", 0.2)][1], out[("1", 0.2)][2], 5, len(bank)), want, "split thr=0.2 cap=50")
     assert (out[("1", 0.2)][0] == 50).any()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_extreme_thresholds(scanner, bank_x2, mode):
+    """NaN / +inf thresholds emit nothing (the reference's `sim > thr` is false), -inf behaves like -1."""
+    bank = bank_x2.subset([40, 41, 95 + 40])
+    page = np.random.default_rng(9).integers(0, 256, (70, 120), dtype=np.uint8)
+    scanner.set_bank(bank)
+    scanner.set_pages(page)
+    for thr in (float("nan"), float("inf"), 2.0):
+        scanner.scan(thr, 1024, mode)
+        assert scanner.total_matches() == 0
+        scanner.process_hits(0.95, 5)
+        assert scanner.lines() == [[]]
+    scanner.scan(float("-inf"), 64, mode)
+    a = scanner.matches()[1].copy()
+    scanner.scan(-1.0, 64, mode)
+    assert a.tobytes() == scanner.matches()[1].tobytes() and len(a) > 0

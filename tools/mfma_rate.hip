@@ -4,10 +4,10 @@
 #include <cstdlib>
 typedef int v4i __attribute__((ext_vector_type(4)));
 template <int MODE, int MT, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void k(const v4i* __restrict__ src, int* __restrict__ out, int iters, int ntiles) {
+__global__ __launch_bounds__(NW * 64, NW / 4) void k(const v4i* __restrict__ src, const v4i* __restrict__ bsrc, int* __restrict__ out, int iters, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4i* bank = (v4i*)smem;
-    for (int i = threadIdx.x; i < ntiles * 3 * 64; i += NW * 64) bank[i] = src[i % 4096];
+    for (int i = threadIdx.x; i < ntiles * 3 * 64; i += NW * 64) bank[i] = bsrc[i % 4096];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     v4i a[MT][3], nl[MT];
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k(const v4i* __restrict__ src
     if (found == 12345) out[threadIdx.x] = found;
 }
 template <int MODE, int MT, int NW>
-void run(const v4i* d, int* o, const char* name) {
+void run(const v4i* d, const v4i* db, int* o, const char* name) {
     const int ntiles = 24, iters = 200;
     size_t lds = ntiles * 3 * 1024;
     auto kern = k<MODE, MT, NW>;
@@ -48,24 +48,30 @@ void run(const v4i* d, int* o, const char* name) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, 0, d, o, iters, ntiles);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, 0, d, db, o, iters, ntiles);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double mf = 256.0 * NW * iters * ntiles * 3 * MT;
         if (rep == 2) printf("%s: %.3f ms, %.1f G MFMA/s, %.2f cycles/MFMA/SIMD @2.4GHz, %.1f TMAC/s\n", name, ms, mf / ms / 1e6, 1024 * 2.4e9 / (mf / (ms * 1e-3)), mf * 16384 / ms / 1e9);
     }
 }
-int main() {
+int main(int argc, char** argv) {
     v4i* d; int* o; hipMalloc(&d, 4096 * 16); hipMalloc(&o, 4096);
     unsigned* h = (unsigned*)malloc(4096 * 16); srand(1); for (int i = 0; i < 4096 * 4; i++) h[i] = rand() * 2654435761u;
+    // optional: argv[1] = hex byte pattern for the A operands (first 1536 v4i = a[][] sources), e.g. 80 or 00
+    if (argc > 1) { unsigned b = strtoul(argv[1], 0, 16) & 0xff; unsigned w = b * 0x01010101u; int frac = argc > 2 ? atoi(argv[2]) : 100;
+        for (int i = 0; i < 4096 * 4; i++) if ((rand() % 100) < frac) h[i] = w; printf("A/B words set to 0x%08x with probability %d%%\n", w, frac); }
+    v4i* db; hipMalloc(&db, 4096 * 16);
+    { unsigned* hb = (unsigned*)malloc(4096 * 16); srand(7); for (int i = 0; i < 4096 * 4; i++) { int v[4]; for (int q = 0; q < 4; q++) v[q] = (rand() % 3 == 0) ? 0 : (rand() % 61 - 30); hb[i] = (v[0] & 0xff) | ((v[1] & 0xff) << 8) | ((v[2] & 0xff) << 16) | ((unsigned)(v[3] & 0xff) << 24); }
+      hipMemcpy(db, hb, 4096 * 16, hipMemcpyHostToDevice); }  // B: template-like small ints, a third zeros
     hipMemcpy(d, h, 4096 * 16, hipMemcpyHostToDevice);
-    run<0, 8, 8>(d, o, "mfma only      MT8 NW8 ");
-    run<1, 8, 8>(d, o, "+ B reload     MT8 NW8 ");
-    run<2, 8, 8>(d, o, "+ max/ballot   MT8 NW8 ");
-    run<0, 4, 16>(d, o, "mfma only      MT4 NW16");
-    run<2, 4, 16>(d, o, "+ all          MT4 NW16");
-    run<2, 6, 12>(d, o, "+ all          MT6 NW12");
-    run<0, 8, 4>(d, o, "mfma only      MT8 NW4 ");
-    run<2, 8, 4>(d, o, "+ all          MT8 NW4 ");
+    run<0, 8, 8>(d, db, o, "mfma only      MT8 NW8 ");
+    run<1, 8, 8>(d, db, o, "+ B reload     MT8 NW8 ");
+    run<2, 8, 8>(d, db, o, "+ max/ballot   MT8 NW8 ");
+    run<0, 4, 16>(d, db, o, "mfma only      MT4 NW16");
+    run<2, 4, 16>(d, db, o, "+ all          MT4 NW16");
+    run<2, 6, 12>(d, db, o, "+ all          MT6 NW12");
+    run<0, 8, 4>(d, db, o, "mfma only      MT8 NW4 ");
+    run<2, 8, 4>(d, db, o, "+ all          MT8 NW4 ");
     return 0;
 }
