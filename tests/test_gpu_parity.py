@@ -337,3 +337,47 @@ def test_extreme_thresholds(scanner, bank_x2, mode):
     a = scanner.matches()[1].copy()
     scanner.scan(-1.0, 64, mode)
     assert a.tobytes() == scanner.matches()[1].tobytes() and len(a) > 0
+
+
+def test_fuzz_geometry_banks_thresholds(scanner):
+    """Seeded fuzz over page geometry, bank shapes (all K layouts, class mixes), thresholds and caps; both device
+    paths against the oracle, plus process_hits against the oracle's on the same lists."""
+    rng = np.random.default_rng(20261004)
+    for it in range(150):
+        n_classes = int(rng.integers(1, 4))
+        shapes = [(int(rng.integers(1, 17)), int(rng.integers(1, 33))) for _ in range(n_classes)]
+        if it % 4 == 0:
+            shapes = [(int(rng.integers(8, 13)), int(rng.choice([14, 15, 16]))) for _ in range(n_classes)]  # font-like
+        bank = _random_bank(rng, shapes, int(rng.integers(1, 24)))
+        n_pages = int(rng.integers(1, 5))
+        r_w = int(rng.integers(max(s[0] for s in shapes) + 1, 150))
+        r_h = int(rng.integers(max(s[1] for s in shapes) + 1, 90))
+        pages = rng.integers(0, 256, (n_pages, r_h, r_w), dtype=np.uint8)
+        if it % 3 == 0:
+            pages[rng.random(pages.shape) < 0.85] = 255  # mostly paper: exercises the blank-tile skip
+        for k in range(0, len(bank), 3):  # plant some templates
+            nd = bank.needle(k)
+            p, y, x = int(rng.integers(0, n_pages)), int(rng.integers(0, max(1, r_h - nd.shape[0]))), int(rng.integers(0, max(1, r_w - nd.shape[1])))
+            h, w = min(nd.shape[0], r_h - y), min(nd.shape[1], r_w - x)
+            pages[p, y:y + h, x:x + w] = 255 - nd[:h, :w]
+        thr = float(rng.choice([-0.5, 0.1, 0.4, 0.8, 0.97]))
+        cap = int(rng.choice([1, 2, 37, 1024]))
+        scanner.set_bank(bank)
+        scanner.set_pages(pages)
+        want = _oracle_lists(pages, bank, thr, cap)
+        for mode in (SCAN_MFMA, SCAN_DIRECT):
+            scanner.scan(thr, cap, mode)
+            offsets, m = scanner.matches()
+            _assert_same(_csr_to_lists(offsets, m, n_pages, len(bank)), want, f"fuzz {it} shapes={shapes} {r_w}x{r_h} thr={thr} cap={cap} mode={mode}")
+        scanner.process_hits(0.6, 3)
+        lines = scanner.lines()
+        for p in range(n_pages):
+            counts = np.array([len(x) for x in want[p]], np.uint32)
+            mm = np.zeros((len(bank), max(cap, 1)), O.MATCH_DTYPE)
+            for t, x in enumerate(want[p]):
+                mm[t, : len(x)] = x
+            wl = O.process_hits(O.raw_hits(counts, mm, bank), 0.6, 3)
+            assert len(lines[p]) == len(wl), (it, p)
+            for lg, lw in zip(lines[p], wl):
+                assert np.array_equal(lg["x"].astype(np.int64), lw["x"].astype(np.int64)) and np.array_equal(lg["letter"], lw["letter"])
+                assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
