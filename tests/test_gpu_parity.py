@@ -177,6 +177,7 @@ def test_process_hits_vs_oracle_on_batch(scanner, bank_x2, mode):
                 assert np.array_equal(lg["y"].astype(np.int64), lw["y"].astype(np.int64))
                 assert np.array_equal(lg["letter"], lw["letter"])
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
+                total_chars += len(lg)
 
 
 def test_full_size_c2_properties(scanner, bank_x2):
@@ -343,6 +344,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
     """Seeded fuzz over page geometry, bank shapes (all K layouts, class mixes), thresholds and caps; both device
     paths against the oracle, plus process_hits against the oracle's on the same lists."""
     rng = np.random.default_rng(20261004)
+    total_matches = total_chars = capped = 0
     for it in range(150):
         n_classes = int(rng.integers(1, 4))
         shapes = [(int(rng.integers(1, 17)), int(rng.integers(1, 33))) for _ in range(n_classes)]
@@ -369,6 +371,8 @@ def test_fuzz_geometry_banks_thresholds(scanner):
             scanner.scan(thr, cap, mode)
             offsets, m = scanner.matches()
             _assert_same(_csr_to_lists(offsets, m, n_pages, len(bank)), want, f"fuzz {it} shapes={shapes} {r_w}x{r_h} thr={thr} cap={cap} mode={mode}")
+            total_matches += len(m)
+            capped += int((scanner.counts() == cap).sum())
         scanner.process_hits(0.6, 3)
         lines = scanner.lines()
         for p in range(n_pages):
@@ -381,3 +385,5 @@ def test_fuzz_geometry_banks_thresholds(scanner):
             for lg, lw in zip(lines[p], wl):
                 assert np.array_equal(lg["x"].astype(np.int64), lw["x"].astype(np.int64)) and np.array_equal(lg["letter"], lw["letter"])
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
+                total_chars += len(lg)
+    assert total_matches > 20000 and total_chars > 500 and capped > 100, (total_matches, total_chars, capped)
