@@ -143,6 +143,7 @@ struct focr_ctx {
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch
+    DevBuf post_line_be;
     DevBuf post_keep, post_choice, post_owner, post_packed, post_scanned, post_page_off, post_line_off, post_chars;
     bool lines_on_host = false;
     bool processed = false;

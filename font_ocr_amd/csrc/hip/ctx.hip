@@ -109,6 +109,7 @@ static void free_results(focr_ctx *c) {
     free_dev(c->d_seg_start);
     free_dev(c->d_seg_offset);
     free_dev(c->d_matches);
+    c->post_line_be.release();
     for (auto *b : {&c->post_keep, &c->post_choice, &c->post_owner, &c->post_packed, &c->post_scanned, &c->post_page_off,
                     &c->post_line_off, &c->post_chars})
         b->release();

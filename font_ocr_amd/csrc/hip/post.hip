@@ -22,16 +22,21 @@ __device__ __forceinline__ int32_t total_key(float f) {  // f32::total_cmp as a 
     return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1);
 }
 
-// (1) keep_y: rows with a kept hit of similarity >= anchor_threshold
+// (1) keep_y: rows with a kept hit of similarity >= anchor_threshold; also the extent of every (page, row) line in
+// the sorted hit list (one thread per hit looks at its neighbours), so that the line walk needs no search.
 __global__ void mark_anchor_rows(const uint64_t *__restrict__ hkeys, const float *__restrict__ hsims, const uint8_t *__restrict__ keep,
-                                 size_t n, KeyFmt fmt, float anchor, uint32_t r_h, uint8_t *__restrict__ keep_row) {
+                                 size_t n, KeyFmt fmt, float anchor, uint32_t r_h, uint8_t *__restrict__ keep_row,
+                                 uint32_t *__restrict__ line_b, uint32_t *__restrict__ line_e) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keep[i]) return;
-    if (hsims[i] >= anchor) keep_row[(size_t)fmt.page(hkeys[i]) * r_h + fmt.y(hkeys[i])] = 1;
+    if (i >= n) return;
+    const uint64_t k = hkeys[i];
+    const size_t row = (size_t)fmt.page(k) * r_h + fmt.y(k);
+    if (i == 0 || fmt.line(hkeys[i - 1]) != fmt.line(k)) line_b[row] = (uint32_t)i;
+    if (i + 1 == n || fmt.line(hkeys[i + 1]) != fmt.line(k)) line_e[row] = (uint32_t)(i + 1);
+    if (keep[i] && hsims[i] >= anchor) keep_row[row] = 1;
 }
 
-// One wave per (page, row): finds the row's extent in the (page, y, x, t)-sorted hit list by binary search, then
-// walks it 64 elements at a time.  Hits cut off by the per-call cap (keep[i] == 0) are not part of the reference's
+// One wave per anchored (page, row): walks the row's extent of the (page, y, x, t)-sorted hit list 64 elements at a time.  Hits cut off by the per-call cap (keep[i] == 0) are not part of the reference's
 // all_hits and are transparent here.  Groups are anchored on their first element (partition_by keeps `last` until
 // a group closes, src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave
 // operations: ballot for the group's extent inside the chunk, a 64-bit max-reduction for the winner (key =
@@ -40,27 +45,13 @@ __global__ void mark_anchor_rows(const uint64_t *__restrict__ hkeys, const float
 __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims,
                                                   const uint8_t *__restrict__ keep, size_t n, KeyFmt fmt, uint32_t r_h,
                                                   uint32_t n_rows_total, int32_t overlap, const uint8_t *__restrict__ keep_row,
+                                                  const uint32_t *__restrict__ line_b, const uint32_t *__restrict__ line_e,
                                                   uint32_t *__restrict__ choice, uint32_t *__restrict__ owner,
                                                   uint64_t *__restrict__ packed) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_rows_total) return;
     if (!keep_row[wave]) return;  // keep_row is [page][y] with pitch r_h == wave index
-    const uint64_t line = ((uint64_t)(wave / r_h) << fmt.by) | (uint64_t)(wave % r_h);  // (page, y) as the key packs it
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {  // first element of the line
-        uint64_t mid = (lo + hi) >> 1;
-        if (fmt.line(keys[mid]) < line) lo = mid + 1;
-        else hi = mid;
-    }
-    const uint64_t b = lo;
-    hi = n;
-    while (lo < hi) {  // one past its last element
-        uint64_t mid = (lo + hi) >> 1;
-        if (fmt.line(keys[mid]) <= line) lo = mid + 1;
-        else hi = mid;
-    }
-    const uint64_t e = lo;
-    if (b == e) return;
+    const uint64_t b = line_b[wave], e = line_e[wave];  // written by mark_anchor_rows for every row that has hits
 
     uint32_t groups = 0;
     bool open = false;   // a group is open (carried across chunks)
@@ -189,16 +180,17 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, n * 8);
     uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, n * 8);
     uint64_t *d_page_off = (uint64_t *)c->post_page_off.ensure(c, (n_pages + 1) * 8);
-    if (!keep_row || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    uint32_t *line_b = (uint32_t *)c->post_line_be.ensure(c, n_rows_total * 8), *line_e = line_b ? line_b + n_rows_total : nullptr;
+    if (!line_b || !keep_row || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
     const uint8_t *keep = (const uint8_t *)c->ord_keep.p;
     FOCR_HIP(c, hipMemsetAsync(keep_row, 0, n_rows_total, c->stream));
     FOCR_HIP(c, hipMemsetAsync(owner, 0xff, n * 4, c->stream));
     FOCR_HIP(c, hipMemsetAsync(packed, 0, n * 8, c->stream));
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, n, c->fmt, anchor_threshold,
-                       (uint32_t)c->r_h, keep_row);
+                       (uint32_t)c->r_h, keep_row, line_b, line_e);
     hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
-                       keep, n, c->fmt, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep_row, choice, owner, packed);
+                       keep, n, c->fmt, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep_row, line_b, line_e, choice, owner, packed);
     int rc;
     if ((rc = exclusive_scan_u64(c, packed, scanned, n))) return rc;
     uint64_t last_scan = 0, last_packed = 0;

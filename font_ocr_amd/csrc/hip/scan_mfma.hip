@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
     for (int k = 0; k < 4; k++)
         keep[k] = c.n_w >= (uint32_t)(4 * k + 4) ? -1 : (c.n_w <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (c.n_w - 4 * k))) - 1u));
     uint32_t acc = 0, s_p = 0, s2_p = 0;
+#pragma unroll 8
     for (uint32_t j = 0; j < c.n_h; j++) {
         const v4i a = *reinterpret_cast<const v4i_u *>(pg + (size_t)j * pitch) & keep;
         const v4i b = nd[j];

@@ -177,7 +177,6 @@ def test_process_hits_vs_oracle_on_batch(scanner, bank_x2, mode):
                 assert np.array_equal(lg["y"].astype(np.int64), lw["y"].astype(np.int64))
                 assert np.array_equal(lg["letter"], lw["letter"])
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
-                total_chars += len(lg)
 
 
 def test_full_size_c2_properties(scanner, bank_x2):
