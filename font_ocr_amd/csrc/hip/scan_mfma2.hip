@@ -211,15 +211,26 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
 
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     const uint32_t ks = L.ksteps, rpg = L.layout;
-    int cfg = 3;  // FOCR_MFMA_CFG: 3 = 16 waves x MT 4 (default, measured best), 0 = 8 waves x MT 8, 1 = 12 waves x MT 6, 2 = 12 waves x MT 8
+    // 16 waves x 4 M-tiles per CU measured best for <= 4 K-steps (8 x 8 and 12 x 6 were 6-9 % slower at C2); the
+    // 5..8 K-step layouts need the registers of 8 waves per CU.  -DFOCR_MFMA_EXPERIMENTS compiles the alternatives
+    // back in (selected with FOCR_MFMA_CFG = 0: 8 x 8, 1: 12 x 6).
+#ifdef FOCR_MFMA_EXPERIMENTS
+    int cfg = 3;
     if (const char *e = getenv("FOCR_MFMA_CFG")) cfg = atoi(e);
 #define CASE(K, R, M)                                                  \
     case (K) * 10 + (R):                                               \
         if (cfg == 1 && (K) <= 4) launch_v2<K, R, 6, 12>(c, L, n_cus);      \
-        else if (cfg == 2 && (K) <= 2) launch_v2<K, R, 8, 12>(c, L, n_cus); \
-        else if (cfg == 3 && (K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus); \
+        else if (cfg == 0 && (K) <= 4) launch_v2<K, R, 8, 8>(c, L, n_cus);  \
+        else if ((K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus);        \
         else launch_v2<K, R, M, 8>(c, L, n_cus);                       \
         break;
+#else
+#define CASE(K, R, M)                                           \
+    case (K) * 10 + (R):                                        \
+        if ((K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus);      \
+        else launch_v2<K, R, M, 8>(c, L, n_cus);                \
+        break;
+#endif
     switch (ks * 10 + rpg) {
         CASE(1, 1, 8) CASE(2, 1, 8) CASE(3, 1, 8) CASE(4, 1, 8) CASE(5, 1, 4) CASE(6, 1, 4) CASE(7, 1, 4) CASE(8, 1, 4)
         CASE(1, 2, 8) CASE(2, 2, 8) CASE(3, 2, 8) CASE(4, 2, 8)
