@@ -233,14 +233,31 @@ def main():
         t0 = time.perf_counter()
         total, _, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
         cdt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.scan_pages_mt(inv[:2], bank, args.threshold, 1024, use_ref=use_ref, threads=1)  # single-core figure, 2 pages
+        cdt1 = time.perf_counter() - t0
         out["cpu_baseline"] = {
             "value": round(S * R_W * R_H / cdt / 1e6, 4),
             "unit": "Mpx/s",
             "cores": threads,
             "kind": "reference" if use_ref else "port",
-            "sample": f"{S} of the same synthetic pages x 380 templates, one page per thread "
+            "sample": f"{S} of the same synthetic pages x {len(bank)} templates, one page per thread "
                       f"(window tables + kernel calls as src/ncc.rs:231-404), {cdt:.1f} s wall, {int(total)} raw hits",
+            "value_1_core": round(2 * R_W * R_H / cdt1 / 1e6, 4),
         }
+
+    if rank == 0 and args.config == "c2" and not args.noise:
+        # parity in the same run: page 0 of this very batch against the committed reference golden (tests/golden/c2_page0.npz)
+        try:
+            g = np.load(os.path.join(ROOT, "tests", "golden", "c2_page0.npz"))
+            sc.scan(0.8, 1024, mode)
+            offs, m = sc.matches()
+            mine = m[: int(offs[len(bank)])]
+            same = np.array_equal(sc.counts()[0], g["counts"]) and mine.tobytes() == g["matches"].tobytes()
+            out["parity"] = (f"page 0: {len(mine)} raw matches bit-identical to the reference kernel's golden lists" if same
+                             else "MISMATCH against tests/golden/c2_page0.npz")
+        except OSError:
+            out["parity"] = "golden fixture not found"
 
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
