@@ -114,13 +114,28 @@ def main():
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
+    pending = []  # the previous step's gather, still in flight on RCCL's stream while this step scans
+
     def gather_lines():
-        """RCCL gather of the post-processed characters (variable length, device resident) to rank 0."""
+        """RCCL gather of the post-processed characters (variable length, device resident) to rank 0.  Launched
+        asynchronously: it overlaps the next step's scan and is waited for one step later (and before the clock stops)."""
         ptr, cnt = sc.device_chars()
         nbytes = cnt * HIT_DTYPE.itemsize
         mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev) if nbytes else torch.zeros(0, dtype=torch.uint8, device=dev)
-        allc = gather_chars(mine, rank, world, dev)
-        return allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+        torch.cuda.current_stream().synchronize()  # `mine` was produced on the library's stream, already synced by process_hits
+        pending.append(gather_chars(mine, rank, world, dev, async_op=True))
+        n_prev = 0
+        while len(pending) > 1:
+            allc = pending.pop(0)()
+            n_prev = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+        return n_prev
+
+    def drain_gathers():
+        n_last = 0
+        while pending:
+            allc = pending.pop(0)()
+            n_last = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+        return n_last
 
     def step():
         sc.scan(args.threshold, 1024, mode)
@@ -131,6 +146,7 @@ def main():
 
     def fence():
         sc.sync()
+        drain_gathers()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -144,13 +160,15 @@ def main():
     phase = {}
     n_chars = 0
     for _ in range(args.steps):
-        n_chars = step()
+        n_chars = step() or n_chars
         for li in sc.launches():
             k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
             k["ms"] += li["ms"]
             k["n"] += 1
         for k_, v in sc.timings().items():
             phase[k_] = phase.get(k_, 0.0) + v
+    if use_dist:
+        n_chars = drain_gathers() or n_chars
     fence()
     dt = time.perf_counter() - t0
     if use_dist:

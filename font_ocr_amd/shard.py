@@ -17,9 +17,13 @@ def shard_range(n_pages, rank, world):
     return first, min(n_pages, first + per)
 
 
-def gather_chars(mine, rank, world, device=None):
+def gather_chars(mine, rank, world, device=None, async_op=False):
     """Gather every rank's flat uint8 tensor (HIT_DTYPE records) to rank 0 -> one concatenated tensor in rank
-    order on rank 0, None elsewhere.  `mine` may live on the GPU (nccl) or the CPU (gloo)."""
+    order on rank 0, None elsewhere.  `mine` may live on the GPU (nccl) or the CPU (gloo).
+
+    async_op=True returns a zero-argument `finish()` instead: the gather is in flight on the collective's own
+    stream (it reads a private copy of `mine`), so the next batch's scan can overlap it; call finish() to wait and
+    get the result."""
     import torch
     import torch.distributed as dist
 
@@ -32,10 +36,16 @@ def gather_chars(mine, rank, world, device=None):
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[: mine.numel()] = mine
     out = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
-    if rank != 0:
-        return None
-    return torch.cat([out[r][: sizes[r]] for r in range(world)])
+    work = dist.gather(buf, out, dst=0, async_op=async_op)
+
+    def finish():
+        if async_op:
+            work.wait()
+        if rank != 0:
+            return None
+        return torch.cat([out[r][: sizes[r]] for r in range(world)])
+
+    return finish if async_op else finish()
 
 
 def chars_from_bytes(t):
