@@ -36,43 +36,53 @@ __global__ void mark_anchor_rows(const uint64_t *__restrict__ hkeys, const float
     if (keep[i] && hsims[i] >= anchor) keep_row[row] = 1;
 }
 
-// One wave per anchored (page, row): walks the row's extent of the (page, y, x, t)-sorted hit list 64 elements at a time.  Hits cut off by the per-call cap (keep[i] == 0) are not part of the reference's
-// all_hits and are transparent here.  Groups are anchored on their first element (partition_by keeps `last` until
-// a group closes, src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave
-// operations: ballot for the group's extent inside the chunk, a 64-bit max-reduction for the winner (key =
-// total_cmp order of the similarity, then the element index, so the LAST maximum wins, :761-764).
-// Outputs: choice[b + k] = winning element of the k-th group, owner[b + k] = b, packed[b] = 1<<32 | groups.
+// wave64 unsigned max via DPP (row_shr 1/2/4/8, row_bcast 15/31): the result is uniform (read from lane 63)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// One wave per anchored (page, row): walks the row's extent of the (page, y, x, t)-sorted hit list 64 elements at a
+// time.  Hits cut off by the per-call cap (keep[i] == 0) are not part of the reference's all_hits and are transparent
+// here.  Groups are anchored on their first element (partition_by keeps `last` until a group closes,
+// src/ncc.rs:1042-1048), so group boundaries are sequential, but every step is a handful of wave operations: a ballot
+// for the group's extent inside the chunk, a DPP max-reduction of the similarity order (f32::total_cmp), and a ballot
+// of the lanes that reach it — the highest such lane is the LAST maximum, which is what max_by keeps (:761-764).
+// Outputs: choice[b + k] = winning element of the row's k-th group, row_groups[row] = 1<<32 | number of groups.
 __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims,
-                                                  const uint8_t *__restrict__ keep, size_t n, KeyFmt fmt, uint32_t r_h,
-                                                  uint32_t n_rows_total, int32_t overlap, const uint8_t *__restrict__ keep_row,
+                                                  const uint8_t *__restrict__ keep, KeyFmt fmt, uint32_t n_rows_total,
+                                                  int32_t overlap, const uint8_t *__restrict__ keep_row,
                                                   const uint32_t *__restrict__ line_b, const uint32_t *__restrict__ line_e,
-                                                  uint32_t *__restrict__ choice, uint32_t *__restrict__ owner,
-                                                  uint64_t *__restrict__ packed) {
+                                                  uint32_t *__restrict__ choice, uint64_t *__restrict__ row_groups) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_rows_total) return;
-    if (!keep_row[wave]) return;  // keep_row is [page][y] with pitch r_h == wave index
+    if (!keep_row[wave]) return;  // keep_row / line_b / line_e / row_groups are [page][y] with pitch r_h == wave index
     const uint64_t b = line_b[wave], e = line_e[wave];  // written by mark_anchor_rows for every row that has hits
 
     uint32_t groups = 0;
-    bool open = false;   // a group is open (carried across chunks)
-    int32_t anchor = 0;  // x of the open group's first element
-    uint64_t best = 0;   // (total_cmp order) << 32 | element index, of the open group
+    bool open = false;            // a group is open (carried across chunks)
+    int32_t anchor = 0;           // x of the open group's first element
+    uint32_t best_ord = 0, best_idx = 0;  // winner so far of the open group: total_cmp order, element index
     for (uint64_t base = b; base < e; base += 64) {
         const uint64_t i = base + lane;
         const bool valid = i < e && keep[i];
         const int32_t x = valid ? (int32_t)fmt.x(keys[i]) : 0x7fffffff;
         const uint32_t ord = valid ? ((uint32_t)total_key(sims[i]) ^ 0x80000000u) : 0u;  // unsigned order of total_cmp
-        const uint64_t mine = ((uint64_t)ord << 32) | (uint32_t)(i - b);
         const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
-        const bool last_chunk = base + 64 >= e;
         uint32_t pos = 0;  // wave-uniform cursor inside the chunk
         while (pos < 64) {
             if (!open) {
                 const uint64_t cand = vmask & (~0ull << pos);  // the next kept element opens a group
                 if (!cand) break;
                 pos = (uint32_t)__builtin_ctzll(cand);
-                anchor = __shfl(x, (int)pos);
-                best = 0;
+                anchor = __builtin_amdgcn_readlane(x, (int)pos);
+                best_ord = 0;
+                best_idx = 0;
                 open = true;
             }
             // kept members of the open group at/after pos; the first kept non-member closes it
@@ -80,49 +90,45 @@ __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ k
             const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
             const uint64_t brk = vmask & ~inmask & (~0ull << pos);
             const uint32_t stop = brk ? (uint32_t)__builtin_ctzll(brk) : 64u;
-            uint64_t v = (in && lane < stop) ? mine : 0;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint32_t vlo = __shfl_xor((uint32_t)v, o), vhi = __shfl_xor((uint32_t)(v >> 32), o);
-                const uint64_t other = ((uint64_t)vhi << 32) | vlo;
-                v = other > v ? other : v;
+            const bool member = in && lane < stop;
+            const uint32_t mx = wave_umax(member ? ord : 0u);
+            const uint64_t top = __builtin_amdgcn_ballot_w64(member && ord == mx);
+            if (top && mx >= best_ord) {  // later elements win ties: this chunk's members come after the carried ones
+                best_ord = mx;
+                best_idx = (uint32_t)(base - b) + (63u - (uint32_t)__builtin_clzll(top));
             }
-            if (v > best) best = v;
             if (stop < 64) {  // the group closes inside this chunk
-                if (lane == 0) {
-                    choice[b + groups] = (uint32_t)(b + (uint32_t)best);
-                    owner[b + groups] = (uint32_t)b;
-                }
+                if (lane == 0) choice[b + groups] = (uint32_t)b + best_idx;
                 groups++;
                 open = false;
             }
             pos = stop;
         }
-        if (last_chunk && open) {  // the line ends with a group still open
-            if (lane == 0) {
-                choice[b + groups] = (uint32_t)(b + (uint32_t)best);
-                owner[b + groups] = (uint32_t)b;
-            }
-            groups++;
-            open = false;
-        }
     }
-    if (lane == 0) packed[b] = ((uint64_t)1 << 32) | groups;
+    if (open) {  // the row ends with a group still open
+        if (lane == 0) choice[b + groups] = (uint32_t)b + best_idx;
+        groups++;
+    }
+    if (lane == 0) row_groups[wave] = ((uint64_t)1 << 32) | groups;
 }
 
-// one thread per output character
-__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n, KeyFmt fmt,
-                           const uint32_t *__restrict__ choice, const uint32_t *__restrict__ owner,
+// one thread per hit slot: slot i of a row is the row's (i - line_b)-th output character if the row has that many groups
+__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n, KeyFmt fmt, uint32_t r_h,
+                           const uint8_t *__restrict__ keep_row, const uint32_t *__restrict__ line_b,
+                           const uint32_t *__restrict__ choice, const uint64_t *__restrict__ row_groups,
                            const uint64_t *__restrict__ scanned, const uint32_t *__restrict__ t_w,
                            const uint32_t *__restrict__ t_h, const uint32_t *__restrict__ t_letter,
                            uint64_t *__restrict__ line_char_off, focr_hit_t *__restrict__ chars) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t ls = owner[i];
-    if (ls == 0xffffffffu) return;
-    const uint64_t sc = scanned[ls];
-    const uint64_t off = (sc & 0xffffffffu) + (i - ls);
-    if (i == ls) line_char_off[sc >> 32] = sc & 0xffffffffu;
+    const uint64_t ki = keys[i];
+    const size_t row = (size_t)fmt.page(ki) * r_h + fmt.y(ki);
+    if (!keep_row[row]) return;
+    const uint32_t k = (uint32_t)i - line_b[row];
+    if (k >= (uint32_t)row_groups[row]) return;
+    const uint64_t sc = scanned[row];
+    const uint64_t off = (sc & 0xffffffffu) + k;
+    if (k == 0) line_char_off[sc >> 32] = sc & 0xffffffffu;
     const uint32_t e = choice[i];
     const uint64_t key = keys[e];
     const uint32_t t = fmt.t(key);
@@ -137,18 +143,12 @@ __global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__res
     chars[off] = h;
 }
 
-// page_line_off[p] = number of kept lines on pages < p
-__global__ void page_offsets(const uint64_t *__restrict__ keys, size_t n, KeyFmt fmt, const uint64_t *__restrict__ scanned,
-                             uint64_t total_lines, uint32_t n_pages, uint64_t *__restrict__ page_line_off) {
+// page_line_off[p] = number of kept lines on pages < p = the row scan at the page's first row
+__global__ void page_offsets(const uint64_t *__restrict__ scanned, uint32_t r_h, uint64_t total_lines, uint32_t n_pages,
+                             uint64_t *__restrict__ page_line_off) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_pages) return;
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
-        if (fmt.page(keys[mid]) < p) lo = mid + 1;
-        else hi = mid;
-    }
-    page_line_off[p] = lo < n ? (scanned[lo] >> 32) : total_lines;
+    page_line_off[p] = p < n_pages ? (scanned[(size_t)p * r_h] >> 32) : total_lines;
 }
 
 }  // namespace focr
@@ -176,37 +176,33 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     const size_t n_rows_total = n_pages * c->r_h;
     uint8_t *keep_row = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
     uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, n * 4);
-    uint32_t *owner = (uint32_t *)c->post_owner.ensure(c, n * 4);
-    uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, n * 8);
-    uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, n * 8);
+    uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, (n_rows_total + 1) * 8);    // per row: 1<<32 | groups
+    uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, (n_rows_total + 1) * 8);
     uint64_t *d_page_off = (uint64_t *)c->post_page_off.ensure(c, (n_pages + 1) * 8);
     uint32_t *line_b = (uint32_t *)c->post_line_be.ensure(c, n_rows_total * 8), *line_e = line_b ? line_b + n_rows_total : nullptr;
-    if (!line_b || !keep_row || !choice || !owner || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    if (!line_b || !keep_row || !choice || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
     const uint8_t *keep = (const uint8_t *)c->ord_keep.p;
     FOCR_HIP(c, hipMemsetAsync(keep_row, 0, n_rows_total, c->stream));
-    FOCR_HIP(c, hipMemsetAsync(owner, 0xff, n * 4, c->stream));
-    FOCR_HIP(c, hipMemsetAsync(packed, 0, n * 8, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(packed, 0, (n_rows_total + 1) * 8, c->stream));
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, n, c->fmt, anchor_threshold,
                        (uint32_t)c->r_h, keep_row, line_b, line_e);
     hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
-                       keep, n, c->fmt, (uint32_t)c->r_h, (uint32_t)n_rows_total, overlap, keep_row, line_b, line_e, choice, owner, packed);
+                       keep, c->fmt, (uint32_t)n_rows_total, overlap, keep_row, line_b, line_e, choice, packed);
     int rc;
-    if ((rc = exclusive_scan_u64(c, packed, scanned, n))) return rc;
-    uint64_t last_scan = 0, last_packed = 0;
-    FOCR_HIP(c, hipMemcpyAsync(&last_scan, scanned + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
-    FOCR_HIP(c, hipMemcpyAsync(&last_packed, packed + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = exclusive_scan_u64(c, packed, scanned, n_rows_total + 1))) return rc;
+    uint64_t tot = 0;  // packed[n_rows_total] = 0, so the scan's last entry is the grand total
+    FOCR_HIP(c, hipMemcpyAsync(&tot, scanned + n_rows_total, 8, hipMemcpyDeviceToHost, c->stream));
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t tot = last_scan + last_packed;
     c->n_lines = (size_t)(tot >> 32);
     c->n_chars = (size_t)(tot & 0xffffffffu);
     uint64_t *d_line_off = (uint64_t *)c->post_line_off.ensure(c, (c->n_lines + 1) * 8);
     focr_hit_t *d_chars = (focr_hit_t *)c->post_chars.ensure(c, (c->n_chars ? c->n_chars : 1) * sizeof(focr_hit_t));
     if (!d_line_off || !d_chars) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
-    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, n, c->fmt, choice, owner, scanned,
-                       c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
-    hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, n, c->fmt,
-                       scanned, (uint64_t)c->n_lines, (uint32_t)n_pages, d_page_off);
+    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, n, c->fmt, (uint32_t)c->r_h, keep_row,
+                       line_b, choice, packed, scanned, c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
+    hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, scanned, (uint32_t)c->r_h,
+                       (uint64_t)c->n_lines, (uint32_t)n_pages, d_page_off);
     FOCR_HIP(c, hipGetLastError());
     FOCR_HIP(c, hipEventRecord(c->ev[6], c->stream));
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
