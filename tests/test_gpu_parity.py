@@ -386,3 +386,32 @@ def test_fuzz_geometry_banks_thresholds(scanner):
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
                 total_chars += len(lg)
     assert total_matches > 20000 and total_chars > 500 and capped > 100, (total_matches, total_chars, capped)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("box_size", ["char", "font"])
+def test_box_size_char_and_font_banks(scanner, mode, box_size):
+    """--box-size char gives every glyph its own tight box (dozens of size classes, src/ncc.rs:627); --box-size
+    font one large box (src/ncc.rs:589-599).  Both go through the same scan."""
+    import os
+
+    from font_ocr_amd import Bank
+
+    font = "/usr/share/fonts/truetype/dejavu/DejaVuSansMono.ttf"
+    if not os.path.exists(font):
+        pytest.skip("DejaVu Sans Mono not installed")
+    alphabet = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789.,;:-_"
+    bank = Bank.rasterize(font, 11 if box_size == "font" else 13, 1, 0, alphabet=alphabet, box_size=box_size)
+    if int(bank.templates["n_w"].max()) > 16:
+        pytest.skip("font box wider than 16 px at this size")
+    n_classes = len({(int(t["n_w"]), int(t["n_h"])) for t in bank.templates})
+    assert n_classes >= (10 if box_size == "char" else 1)
+    ref_bank = Bank.rasterize(font, 11 if box_size == "font" else 13, 1, 0, alphabet=alphabet)  # page content
+    pages = np.stack([synth_page(ref_bank, SYNTH_SEED_BASE + 700 + p, 300, 110) for p in range(2)])
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    scanner.scan(0.7, 1024, mode)
+    offsets, m = scanner.matches()
+    want = _oracle_lists(pages, bank, 0.7, 1024)
+    _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want, f"box_size={box_size}")
+    assert sum(len(x) for p in want for x in p) > 100
