@@ -19,7 +19,8 @@ namespace focr {
 struct SizeClass {
     uint32_t n_w, n_h;
     uint32_t ndw;          // dwords per padded template row in the direct kernel (1..4)
-    uint32_t maxh;         // padded row count in the direct kernel (16 or 32)
+    uint32_t maxh;         // padded row count in the direct kernel (16 or 32; = n_h for tall classes)
+    bool tall;             // n_h > 32: scanned by scan_tall_kernel in both modes (no MFMA layout)
     uint32_t n_templates;  // templates in this class
     uint32_t first;        // index of the class's first entry in the class-ordered arrays
     // MFMA prefilter layout

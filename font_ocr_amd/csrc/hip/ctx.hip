@@ -213,11 +213,19 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
     if (device < 0 || device >= n) return fail(nullptr, FOCR_ERR_INVALID, "focr_ctx_create: bad device index");
     focr_ctx *c = new focr_ctx();
     c->device = device;
-    FOCR_HIP(c, hipSetDevice(device));
-    FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
-    FOCR_HIP(c, hipMalloc(&c->d_counter, 64 * sizeof(uint32_t)));
-    FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+    auto init = [&]() -> int {
+        FOCR_HIP(c, hipSetDevice(device));
+        FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
+        FOCR_HIP(c, hipMalloc(&c->d_counter, 64 * sizeof(uint32_t)));
+        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        return FOCR_OK;
+    };
+    int rc = init();
+    if (rc != FOCR_OK) {  // the message is already in focr_last_error_global()
+        focr_ctx_destroy(c);
+        return rc;
+    }
     *out = c;
     return FOCR_OK;
 }
@@ -255,7 +263,7 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
         if (d.n_w == 0 || d.n_h == 0) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: empty template");
         if (d.n_w > 16)  // the reference panics: "not handled", src/ncc.rs:392
             return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template wider than 16 px is not handled (src/ncc.rs:392)");
-        if (d.n_h > 32) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template taller than 32 px is not handled");
+        if (d.n_h > 255) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template taller than 255 px is not handled");
         if ((size_t)d.offset + (size_t)d.n_w * d.n_h > needles_len)
             return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template offset out of range");
     }
@@ -277,7 +285,8 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
             sc.n_w = templates[t].n_w;
             sc.n_h = templates[t].n_h;
             sc.ndw = (sc.n_w + 3) / 4;
-            sc.maxh = sc.n_h <= 16 ? 16 : 32;
+            sc.tall = sc.n_h > 32;
+            sc.maxh = sc.tall ? sc.n_h : (sc.n_h <= 16 ? 16 : 32);
             c->classes.push_back(sc);
             members.emplace_back();
         }
@@ -594,23 +603,25 @@ int focr_debug_rnorm(focr_ctx_t *c, const uint32_t *s, const uint64_t *s2, const
     uint32_t *ds = nullptr, *dn = nullptr;
     uint64_t *ds2 = nullptr;
     double *dout = nullptr;
-    FOCR_HIP(c, hipMalloc(&ds, n_items * 4));
-    FOCR_HIP(c, hipMalloc(&dn, n_items * 4));
-    FOCR_HIP(c, hipMalloc(&ds2, n_items * 8));
-    FOCR_HIP(c, hipMalloc(&dout, n_items * 8));
-    FOCR_HIP(c, hipMemcpyAsync(ds, s, n_items * 4, hipMemcpyHostToDevice, c->stream));
-    FOCR_HIP(c, hipMemcpyAsync(dn, n, n_items * 4, hipMemcpyHostToDevice, c->stream));
-    FOCR_HIP(c, hipMemcpyAsync(ds2, s2, n_items * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(debug_rnorm_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream, ds, ds2, dn,
-                       n_items, dout);
-    FOCR_HIP(c, hipGetLastError());
-    FOCR_HIP(c, hipMemcpyAsync(out, dout, n_items * 8, hipMemcpyDeviceToHost, c->stream));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(ds);
-    (void)hipFree(dn);
-    (void)hipFree(ds2);
-    (void)hipFree(dout);
-    return FOCR_OK;
+    auto run = [&]() -> int {
+        FOCR_HIP(c, hipMalloc(&ds, n_items * 4));
+        FOCR_HIP(c, hipMalloc(&dn, n_items * 4));
+        FOCR_HIP(c, hipMalloc(&ds2, n_items * 8));
+        FOCR_HIP(c, hipMalloc(&dout, n_items * 8));
+        FOCR_HIP(c, hipMemcpyAsync(ds, s, n_items * 4, hipMemcpyHostToDevice, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(dn, n, n_items * 4, hipMemcpyHostToDevice, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(ds2, s2, n_items * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(debug_rnorm_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream, ds, ds2, dn, n_items,
+                           dout);
+        FOCR_HIP(c, hipGetLastError());
+        FOCR_HIP(c, hipMemcpyAsync(out, dout, n_items * 8, hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        return FOCR_OK;
+    };
+    const int rc = run();
+    for (void *p : {(void *)ds, (void *)dn, (void *)ds2, (void *)dout})
+        if (p) (void)hipFree(p);
+    return rc;
 }
 
 }  // extern "C"

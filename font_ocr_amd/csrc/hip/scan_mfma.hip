@@ -32,6 +32,8 @@ namespace focr {
 
 int ensure_hit_capacity(focr_ctx *c, size_t want);
 int sort_keys_u64(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned end_bit);
+int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float *sims, unsigned long long *counter,
+                     unsigned long long capacity);
 int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos, size_t n);
 
 
@@ -224,10 +226,15 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     // K layout per class (mfma_common.h).  Narrow classes ride the 12-byte-row layout whenever a 9..12-wide
     // class exists, so that all of them share one set of A fragments (one "super-class", one kernel pass).
     bool any_mid = false;
-    for (const SizeClass &sc : c->classes) any_mid |= (sc.n_w >= 9 && sc.n_w <= 12);
+    for (const SizeClass &sc : c->classes) any_mid |= (!sc.tall && sc.n_w >= 9 && sc.n_w <= 12);
     c->supers.clear();
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
+        if (sc.tall) {  // scanned exactly by scan_tall_kernel; no quantised copy
+            sc.layout = LAYOUT_W16;
+            sc.k_groups = sc.n_tiles16 = 0;
+            continue;
+        }
         sc.layout = sc.n_w >= 13 ? LAYOUT_W16 : (any_mid ? LAYOUT_W12 : LAYOUT_W8);
         if (sc.layout == LAYOUT_W8) sc.k_groups = ((sc.n_h + 1) / 2 + 3) / 4 * 4;   // 2 rows per group
         else if (sc.layout == LAYOUT_W12) sc.k_groups = (sc.n_h + 15) / 16 * 12;    // 16 rows -> 12 groups (3 K-steps)
@@ -266,6 +273,12 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
         const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4;
+        if (sc.tall) {
+            for (uint32_t i = 0; i < sc.n_templates; i++) order_of[c->h_tconst[sc.first + i].index] = sc.first + i;
+            c->mfma_c_scale.push_back(1.0);
+            c->mfma_e_max.push_back(0.0);
+            continue;
+        }
         // bank-wide scale: 126 / max |b - mean| / norm_n over live templates
         double max_ratio = 0.0;
         std::vector<double> norm_n(sc.n_templates, 0.0), mean(sc.n_templates, 0.0);
@@ -498,6 +511,14 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 t0 = t1;
             }
         }
+        // tall classes: exact scan straight into the candidate list
+        for (size_t k = 0; k < c->classes.size(); k++) {
+            const SizeClass &sc = c->classes[k];
+            if (!sc.tall || sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
+            if ((rc = launch_scan_tall(c, k, thr_d, c->d_cand, nullptr, (unsigned long long *)c->d_counter + 1,
+                                       (unsigned long long)c->cand_capacity)))
+                return rc;
+        }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
         unsigned long long n_cand = 0;
         uint32_t live_counts[40] = {0};
@@ -506,8 +527,10 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipStreamSynchronize(c->stream));
         c->counters[3] = 0;
         for (focr_launch_info_t &li : c->launches) {  // issued MACs follow the number of live M-tiles (known only now)
-            li.issued_macs *= live_counts[li.n_templates >> 24];
-            li.n_templates &= 0xffffff;
+            if (strncmp(li.name, "scan_mfma2", 10) == 0) {
+                li.issued_macs *= live_counts[li.n_templates >> 24];
+                li.n_templates &= 0xffffff;
+            }
             c->counters[3] += li.issued_macs;
         }
         if (n_cand > c->cand_capacity) {

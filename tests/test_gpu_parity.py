@@ -236,7 +236,9 @@ def _random_bank(rng, shapes, per_shape):
     [(8, 15), (5, 9), (3, 3), (1, 1), (8, 32)],  # 8-byte rows only (no 9..12-wide class present)
     [(9, 15), (8, 15), (12, 16), (10, 3)],     # 12-byte rows shared by narrow classes
     [(9, 17), (11, 32), (4, 30), (16, 32)],    # tall templates: 6 / 8 K-steps
-], ids=["w16", "w8", "w12", "tall"])
+    [(9, 33), (16, 48), (5, 40), (13, 64), (9, 15)],  # n_h > 32: scan_tall_kernel (plus one MFMA class)
+    [(7, 58), (16, 70)],                       # only tall classes; 70 > page height: never searchable
+], ids=["w16", "w8", "w12", "tall", "taller", "tallest"])
 def test_random_banks_all_layouts(scanner, mode, shapes):
     rng = np.random.default_rng(hash(str(shapes)) % 2**32)
     bank = _random_bank(rng, shapes, 7)
