@@ -87,6 +87,8 @@ HIP_SYMBOLS = {
     "focr_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "focr_pages_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "focr_pages_upload": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "focr_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "focr_host_free": (None, [C.c_void_p]),
     "focr_pages_upload_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "focr_scan": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_int]),
     "focr_get_counts": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -10,6 +10,7 @@
 //   * a page without any hit prints nothing (the reference panics in partition_by, src/ncc.rs:1040).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -228,8 +229,19 @@ bool write_png_gray(const std::string &path, const uint8_t *px, uint32_t w, uint
 
 }  // namespace
 
+struct PhaseClock {  // -v: wall time of each host phase, on stderr
+    bool on;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        auto n = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "phase %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 int main(int argc, char **argv) {
     Args args = parse_args(argc, argv);
+    PhaseClock clk{args.verbose};
     int box = args.box_size == "font" ? FOCR_BOX_FONT : args.box_size == "alphabet" ? FOCR_BOX_ALPHABET : args.box_size == "char" ? FOCR_BOX_CHAR : -1;
     if (box < 0) die("called `Result::unwrap()` on an `Err` value: () (--box-size must be font, alphabet or char)");  // src/ncc.rs:559
     if (args.raw && args.img.size() != 1) die("assertion failed: args.img.len() == 1");  // src/ncc.rs:834
@@ -241,6 +253,7 @@ int main(int argc, char **argv) {
     if (focr_raster_bank(args.font.c_str(), args.text_size, args.x_bits, args.y_bits, args.hinting, alphabet.data(), alphabet.size(),
                          box, args.x_padding, args.y_padding, &bank, err, sizeof err) != 0)
         die(std::string("rasterising the template bank failed: ") + err);
+    clk.lap("bank raster");
     if (args.verbose) {
         fprintf(stderr, "bank: %zu templates (%zu letters x %u x %u sub-pixel offsets), advance %spx\n", bank.n_templates,
                 alphabet.size(), 1u << args.x_bits, 1u << args.y_bits, f32s(bank.advance_px).c_str());
@@ -285,10 +298,12 @@ int main(int argc, char **argv) {
         }
     }
 
+    clk.lap("decode");
     focr_ctx_t *ctx = nullptr;
     if (focr_ctx_create(0, &ctx) != FOCR_OK) die(std::string("no usable GPU: ") + focr_last_error_global());
     CK(ctx, focr_bank_upload(ctx, bank.templates, bank.n_templates, bank.needles, bank.needles_len));
     const int mode = args.rust ? FOCR_SCAN_DIRECT : FOCR_SCAN_MFMA;
+    clk.lap("ctx + bank");
 
     std::vector<std::vector<std::vector<focr_hit_t>>> page_lines(args.img.size());  // [page][line][char]
     for (auto &kv : groups) {
@@ -296,13 +311,16 @@ int main(int argc, char **argv) {
         const std::vector<size_t> &idx = kv.second;
         CK(ctx, focr_pages_alloc(ctx, idx.size(), w, h));
         for (size_t k = 0; k < idx.size(); k++) CK(ctx, focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
+        clk.lap("upload");
         CK(ctx, focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
+        clk.lap("scan");
         const size_t T = bank.n_templates, n_seg = idx.size() * T;
         std::vector<uint64_t> off(n_seg + 1);
         std::vector<focr_match_t> m(focr_total_matches(ctx));
         CK(ctx, focr_get_matches(ctx, off.data(), m.data()));
         for (size_t s = 0; s < n_seg; s++)
             if (off[s + 1] - off[s] == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+        clk.lap("get_matches");
         if (args.verbose) {
             float ms[6];
             focr_last_timings(ctx, ms);
@@ -326,6 +344,7 @@ int main(int argc, char **argv) {
         for (size_t k = 0; k < idx.size(); k++)
             for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++)
                 page_lines[idx[k]].emplace_back(chars.begin() + line_off[l], chars.begin() + line_off[l + 1]);
+        clk.lap("process_hits");
     }
 
     // output, src/ncc.rs:849-877
@@ -342,6 +361,7 @@ int main(int argc, char **argv) {
                 puts(s.c_str());
             }
         }
+    clk.lap("output");
     focr_ctx_destroy(ctx);
     for (auto &p : pages) free(p.px);
     focr_bank_free(&bank);

@@ -424,6 +424,22 @@ int focr_pages_upload(focr_ctx_t *c, size_t first, size_t count, const uint8_t *
     return FOCR_OK;
 }
 
+int focr_host_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return fail(nullptr, FOCR_ERR_INVALID, "focr_host_alloc: bad arguments");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(nullptr, e == hipErrorOutOfMemory ? FOCR_ERR_NOMEM : FOCR_ERR_NO_DEVICE,
+                    std::string("focr_host_alloc: ") + hipGetErrorString(e));
+    }
+    return FOCR_OK;
+}
+
+void focr_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int focr_pages_upload_device(focr_ctx_t *c, size_t first, size_t count, const void *d_luma, int invert) {
     if (!c || !d_luma) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload_device: bad arguments");
     if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_pages_upload_device: call focr_pages_alloc first");

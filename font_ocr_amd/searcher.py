@@ -29,6 +29,32 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class PinnedPages:
+    """(n, r_h, r_w) uint8 array in page-locked host memory (focr_host_alloc): `.array` is a numpy view.
+    Scanner.upload_pages from it is an asynchronous DMA (see include/focr_ncc.h)."""
+
+    def __init__(self, n, r_h, r_w):
+        self._lib = N.hip()
+        p = C.c_void_p()
+        rc = self._lib.focr_host_alloc(n * r_h * r_w, C.byref(p))
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n, r_h, r_w))
+
+    def close(self):
+        if self._p is not None:
+            self.array = None
+            self._lib.focr_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Searcher:
     """Per-page state of the reference (src/ncc.rs:128-141, 231-261) for the drop-in FFI symbols.
 

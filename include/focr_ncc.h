@@ -139,6 +139,13 @@ int focr_pages_alloc(focr_ctx_t *ctx, size_t n_pages, size_t r_w, size_t r_h);
  * ink-high. */
 int focr_pages_upload(focr_ctx_t *ctx, size_t first, size_t count, const uint8_t *luma,
                       int invert);
+/* Page-locked host memory for page pixels.  From such a buffer
+ * focr_pages_upload is one asynchronous DMA on the context's stream: it
+ * returns as soon as the copy is queued, so the host can decode the next batch
+ * (or drive a second context) meanwhile.  The buffer must stay untouched until
+ * the context's next synchronising call returns (focr_sync, focr_scan). */
+int focr_host_alloc(size_t bytes, void **out);
+void focr_host_free(void *p);
 /* Same, from a device pointer (pages already in HBM, e.g. a torch tensor). */
 int focr_pages_upload_device(focr_ctx_t *ctx, size_t first, size_t count, const void *d_luma,
                              int invert);

@@ -417,3 +417,33 @@ def test_box_size_char_and_font_banks(scanner, mode, box_size):
     want = _oracle_lists(pages, bank, 0.7, 1024)
     _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want, f"box_size={box_size}")
     assert sum(len(x) for p in want for x in p) > 100
+
+
+def test_pinned_async_upload_and_second_context(bank_x2):
+    """Double-buffered ingest: pages DMA'd from focr_host_alloc memory on a second context while
+    the first one scans give the same lists as the plain path."""
+    from font_ocr_amd.searcher import PinnedPages
+
+    pages = [np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 700 + 2 * b + p, 260, 90) for p in range(2)]) for b in range(3)]
+    want = [_oracle_lists(pg, bank_x2, 0.8, 1024) for pg in pages]
+    ctxs = [Scanner(0), Scanner(0)]
+    pins = [PinnedPages(2, 90, 260), PinnedPages(2, 90, 260)]
+    try:
+        for c in ctxs:
+            c.set_bank(bank_x2)
+            c.alloc_pages(2, 260, 90)
+        pins[0].array[:] = pages[0]
+        ctxs[0].upload_pages(pins[0].array)
+        for b in range(3):
+            cur, nxt = ctxs[b % 2], ctxs[(b + 1) % 2]
+            if b + 1 < 3:
+                pins[(b + 1) % 2].array[:] = pages[b + 1]  # its previous upload was synced by that context's scan
+                nxt.upload_pages(pins[(b + 1) % 2].array)
+            cur.scan(0.8, 1024, SCAN_MFMA)
+            offsets, m = cur.matches()
+            _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"batch {b}")
+    finally:
+        for c in ctxs:
+            c.close()
+        for p in pins:
+            p.close()

@@ -1,0 +1,75 @@
+"""End-to-end timing of the `ncc` binary on image files (decode + H2D + scan + process_hits + print).
+
+    python tools/cli_e2e.py [--pages 512] [--fmt pgm|png] [--dir /tmp/focr_e2e]
+
+Writes N synthetic C2-style pages (608x720, DejaVu Sans Mono 13 px, x-bits 2 bank) as PGM or PNG files,
+runs font_ocr_amd/bin/ncc over them and prints one JSON line with the wall time and the end-to-end rate.
+SURVEY.md §8(f) rank 3 (image ingest).  The files are written once and reused.
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from font_ocr_amd import ASCII95, Bank, save_pgm, synth_page  # noqa: E402
+from font_ocr_amd.bank import SYNTH_SEED_BASE  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCC = os.path.join(ROOT, "font_ocr_amd", "bin", "ncc")
+FONT = "/usr/share/fonts/truetype/dejavu/DejaVuSansMono.ttf"
+
+
+def save_png(path, img):
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=512)
+    ap.add_argument("--fmt", default="pgm", choices=["pgm", "png"])
+    ap.add_argument("--dir", default="/tmp/focr_e2e")
+    ap.add_argument("--repeat", type=int, default=3)
+    a = ap.parse_args()
+    os.makedirs(a.dir, exist_ok=True)
+    bank = Bank.rasterize(FONT, 13, 2, 0, alphabet=ASCII95)
+    paths = []
+    for p in range(a.pages):
+        path = os.path.join(a.dir, f"p{p:05d}.{a.fmt}")
+        paths.append(path)
+        if not os.path.exists(path):
+            pg = synth_page(bank, SYNTH_SEED_BASE + p, 608, 720)
+            (save_pgm if a.fmt == "pgm" else save_png)(path, pg)
+    cmd = [NCC, "-f", FONT, "-t", "13", "--x-bits", "2", "-a", ASCII95, "-v", "-i"] + paths
+    best, out = None, None
+    for _ in range(a.repeat):
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            print(r.stderr[-2000:], file=sys.stderr)
+            sys.exit(1)
+        if best is None or dt < best:
+            best, out = dt, r
+    px = a.pages * 608 * 720
+    print(json.dumps({"pages": a.pages, "fmt": a.fmt, "wall_s": round(best, 4), "pages_per_s": round(a.pages / best, 1),
+                      "Mpx_per_s": round(px / best / 1e6, 1), "chars": sum(len(l) for l in out.stdout.splitlines()),
+                      "stderr_tail": out.stderr.strip().splitlines()[-14:]}))
+
+
+if __name__ == "__main__":
+    main()
