@@ -11,16 +11,19 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "focr_host.h"
@@ -231,7 +234,7 @@ bool write_png_gray(const std::string &path, const uint8_t *px, uint32_t w, uint
 
 struct PhaseClock {  // -v: wall time of each host phase, on stderr
     bool on;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t = t0;
     void lap(const char *what) {
         auto n = std::chrono::steady_clock::now();
         if (on) fprintf(stderr, "phase %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
@@ -271,99 +274,181 @@ int main(int argc, char **argv) {
     }
     if (args.img.empty()) return 0;
 
-    // pages, grouped by size so that each group is one resident device batch
+    // Pipeline: images are decoded by all host cores in index order, in batches of
+    // kBatch pages; the GPU context comes up meanwhile; the main thread scans batch b while batches b+1.. decode.
+    // Pages of one batch are grouped by size (one resident device batch per size).  Output is produced per page
+    // and written in page order, so the bytes on stdout are those of the reference's sorted print (src/ncc.rs:845-877).
+    const size_t N = args.img.size();
+    size_t kBatch = 256, kAhead = 3;
+    if (const char *e = getenv("FOCR_CLI_BATCH")) kBatch = std::max<size_t>(1, strtoul(e, nullptr, 10));
     struct Page {
         uint8_t *px = nullptr;
         size_t w = 0, h = 0;
+        std::string err;
     };
-    std::vector<Page> pages(args.img.size());
-    std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
-    {  // decode on all host cores (the reference decodes inside its per-page rayon tasks, src/ncc.rs:839-847, 575)
-        std::atomic<size_t> next{0};
-        std::vector<std::string> errs(args.img.size());
-        auto work = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < args.img.size();) {
-                char e[256] = {0};
-                if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, e, sizeof e) != 0) errs[i] = e[0] ? e : "?";
+    std::vector<Page> pages(N);
+    const size_t n_batches = (N + kBatch - 1) / kBatch;
+    std::vector<size_t> left(n_batches);
+    for (size_t b = 0; b < n_batches; b++) left[b] = std::min(kBatch, N - b * kBatch);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t consumed = 0;  // batches the main thread has finished with (guarded by mu)
+    bool stop = false;
+    std::atomic<size_t> next{0};
+    auto decode_worker = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < N;) {
+            const size_t b = i / kBatch;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || b < consumed + kAhead; });  // bound the decoded pages held in memory
+                if (stop) return;
             }
-        };
-        unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)args.img.size()));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-        for (size_t i = 0; i < args.img.size(); i++) {
-            if (!errs[i].empty()) die("cannot open image: " + errs[i]);  // image::open(..).unwrap(), src/ncc.rs:575
-            groups[{pages[i].w, pages[i].h}].push_back(i);
+            char e[256] = {0};
+            if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, e, sizeof e) != 0)
+                pages[i].err = e[0] ? e : "?";
+            std::lock_guard<std::mutex> lk(mu);
+            if (--left[b] == 0) cv.notify_all();
         }
+    };
+    std::vector<std::thread> pool;
+    {
+        unsigned hw = std::min(64u, std::thread::hardware_concurrency());  // more threads only fight over the address space
+        if (const char *e = getenv("FOCR_CLI_THREADS")) hw = (unsigned)strtoul(e, nullptr, 10);
+        unsigned nt = std::max(1u, std::min<unsigned>(hw, (unsigned)std::min<size_t>(N, kBatch * kAhead)));
+        for (unsigned t = 0; t < nt; t++) pool.emplace_back(decode_worker);
     }
+    auto stop_pool = [&]() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : pool) t.join();
+        pool.clear();
+    };
+    auto fatal = [&](const std::string &msg) {  // panic with the decoders stopped first
+        stop_pool();
+        die(msg);
+    };
 
-    clk.lap("decode");
     focr_ctx_t *ctx = nullptr;
-    if (focr_ctx_create(0, &ctx) != FOCR_OK) die(std::string("no usable GPU: ") + focr_last_error_global());
-    CK(ctx, focr_bank_upload(ctx, bank.templates, bank.n_templates, bank.needles, bank.needles_len));
+    if (focr_ctx_create(0, &ctx) != FOCR_OK) fatal(std::string("no usable GPU: ") + focr_last_error_global());
+#define CKF(expr)                                                                    \
+    do {                                                                             \
+        if ((expr) != FOCR_OK) fatal(std::string(#expr) + ": " + focr_last_error(ctx)); \
+    } while (0)
+    CKF(focr_bank_upload(ctx, bank.templates, bank.n_templates, bank.needles, bank.needles_len));
     const int mode = args.rust ? FOCR_SCAN_DIRECT : FOCR_SCAN_MFMA;
     clk.lap("ctx + bank");
 
-    std::vector<std::vector<std::vector<focr_hit_t>>> page_lines(args.img.size());  // [page][line][char]
-    for (auto &kv : groups) {
-        const size_t w = kv.first.first, h = kv.first.second;
-        const std::vector<size_t> &idx = kv.second;
-        CK(ctx, focr_pages_alloc(ctx, idx.size(), w, h));
-        for (size_t k = 0; k < idx.size(); k++) CK(ctx, focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
-        clk.lap("upload");
-        CK(ctx, focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
-        clk.lap("scan");
-        const size_t T = bank.n_templates, n_seg = idx.size() * T;
-        std::vector<uint64_t> off(n_seg + 1);
-        std::vector<focr_match_t> m(focr_total_matches(ctx));
-        CK(ctx, focr_get_matches(ctx, off.data(), m.data()));
-        for (size_t s = 0; s < n_seg; s++)
-            if (off[s + 1] - off[s] == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
-        clk.lap("get_matches");
-        if (args.verbose) {
-            float ms[6];
-            focr_last_timings(ctx, ms);
-            fprintf(stderr, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5], m.size());
+    const size_t T = bank.n_templates;
+    std::string out;  // formatted output of the pages finished so far
+    double ms_wait = 0, ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t p0 = b * kBatch, p1 = std::min(N, p0 + kBatch);
+        auto t0 = now();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return left[b] == 0; });
         }
-        if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order, then exit
-            for (size_t t = 0; t < T; t++) {
-                const focr_template_t &d = bank.templates[t];
-                for (uint64_t q = off[t]; q < off[t + 1]; q++) {
-                    float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
-                    printf("%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x, m[q].y, d.n_w,
-                           d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str());
+        ms_wait += since(t0);
+        std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
+        for (size_t i = p0; i < p1; i++) {
+            if (!pages[i].err.empty()) fatal("cannot open image: " + pages[i].err);  // image::open(..).unwrap(), src/ncc.rs:575
+            groups[{pages[i].w, pages[i].h}].push_back(i);
+        }
+        std::vector<std::string> page_out(p1 - p0);
+        for (auto &kv : groups) {
+            const size_t w = kv.first.first, h = kv.first.second;
+            const std::vector<size_t> &idx = kv.second;
+            t0 = now();
+            CKF(focr_pages_alloc(ctx, idx.size(), w, h));
+            for (size_t k = 0; k < idx.size(); k++) CKF(focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
+            ms_upload += since(t0);
+            t0 = now();
+            CKF(focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
+            ms_scan += since(t0);
+            t0 = now();
+            std::vector<uint32_t> counts(idx.size() * T);
+            CKF(focr_get_counts(ctx, counts.data()));
+            for (uint32_t cnt : counts)
+                if (cnt == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+            if (args.verbose) {
+                float ms[6];
+                focr_last_timings(ctx, ms);
+                fprintf(stderr, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5], focr_total_matches(ctx));
+            }
+            if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order, then exit
+                std::vector<uint64_t> off(idx.size() * T + 1);
+                std::vector<focr_match_t> m(focr_total_matches(ctx));
+                CKF(focr_get_matches(ctx, off.data(), m.data()));
+                for (size_t t = 0; t < T; t++) {
+                    const focr_template_t &d = bank.templates[t];
+                    for (uint64_t q = off[t]; q < off[t + 1]; q++) {
+                        float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
+                        printf("%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x, m[q].y, d.n_w,
+                               d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str());
+                    }
+                }
+                stop_pool();
+                return 0;
+            }
+            CKF(focr_process_hits(ctx, args.anchor_threshold, args.overlap));
+            std::vector<uint64_t> page_off(idx.size() + 1), line_off(focr_total_lines(ctx) + 1);
+            std::vector<focr_hit_t> chars(focr_total_chars(ctx));
+            CKF(focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
+            ms_post += since(t0);
+            t0 = now();
+            for (size_t k = 0; k < idx.size(); k++) {  // output, src/ncc.rs:849-877
+                std::string &s = page_out[idx[k] - p0];
+                for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++) {
+                    for (uint64_t q = line_off[l]; q < line_off[l + 1]; q++) {
+                        const focr_hit_t &c = chars[q];
+                        if (args.csv) {
+                            float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
+                            char row[160];
+                            snprintf(row, sizeof row, "%zu,%u,%s,%s,%u,%u,%u,%u\n", idx[k], c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x,
+                                     c.y, c.w, c.h);
+                            s += row;
+                        } else {
+                            s += utf8_encode(c.letter);
+                        }
+                    }
+                    if (!args.csv) s += '\n';
                 }
             }
-            return 0;
+            ms_format += since(t0);
         }
-        CK(ctx, focr_process_hits(ctx, args.anchor_threshold, args.overlap));
-        std::vector<uint64_t> page_off(idx.size() + 1), line_off(focr_total_lines(ctx) + 1);
-        std::vector<focr_hit_t> chars(focr_total_chars(ctx));
-        CK(ctx, focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
-        for (size_t k = 0; k < idx.size(); k++)
-            for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++)
-                page_lines[idx[k]].emplace_back(chars.begin() + line_off[l], chars.begin() + line_off[l + 1]);
-        clk.lap("process_hits");
+        for (size_t i = p0; i < p1; i++) {
+            out += page_out[i - p0];
+            free(pages[i].px);
+            pages[i].px = nullptr;
+        }
+        if (out.size() > (1u << 20) || b + 1 == n_batches) {
+            fwrite(out.data(), 1, out.size(), stdout);
+            out.clear();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = b + 1;
+        }
+        cv.notify_all();
     }
-
-    // output, src/ncc.rs:849-877
-    for (size_t i = 0; i < page_lines.size(); i++)
-        for (auto &line : page_lines[i]) {
-            if (args.csv) {
-                for (auto &c : line) {
-                    float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
-                    printf("%zu,%u,%s,%s,%u,%u,%u,%u\n", i, c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x, c.y, c.w, c.h);
-                }
-            } else {
-                std::string s;
-                for (auto &c : line) s += utf8_encode(c.letter);
-                puts(s.c_str());
-            }
-        }
-    clk.lap("output");
+    stop_pool();
+    if (args.verbose)
+        fprintf(stderr, "pipeline: %zu batch(es) of <= %zu pages; main thread waited %.2f ms for decode, upload %.2f ms, scan %.2f ms, "
+                        "counts+process_hits+fetch %.2f ms, format %.2f ms\n", n_batches, kBatch, ms_wait, ms_upload, ms_scan, ms_post, ms_format);
+    clk.lap("pages");
+    fflush(stdout);
     focr_ctx_destroy(ctx);
-    for (auto &p : pages) free(p.px);
     focr_bank_free(&bank);
-    return 0;
+    clk.lap("teardown");
+    if (args.verbose)
+        fprintf(stderr, "total since main() %8.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk.t0).count());
+    // Everything is flushed and the context is gone: leave without the HIP runtime's exit handlers (~170 ms).
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }

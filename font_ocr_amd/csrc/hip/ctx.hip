@@ -372,8 +372,15 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
         return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: page side above 65535 px");
     if (n_pages > 65535) return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: more than 65535 pages per batch");
     FOCR_HIP(c, hipSetDevice(c->device));
+    if (c->d_pages && c->r_w == r_w && c->r_h == r_h && n_pages <= c->pages_capacity) {
+        // same geometry, no more pages than before: keep the buffer (its zero padding is never written)
+        c->scanned = c->processed = false;
+        c->n_pages = n_pages;
+        return FOCR_OK;
+    }
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_pages);
+    c->pages_capacity = 0;
     c->scanned = c->processed = false;
     c->n_pages = n_pages;
     c->r_w = r_w;
@@ -386,6 +393,7 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
         c->n_pages = 0;
         return fail(c, FOCR_ERR_NOMEM, "focr_pages_alloc: hipMalloc failed");
     }
+    c->pages_capacity = n_pages;
     FOCR_HIP(c, hipMemsetAsync(c->d_pages, 0, bytes, c->stream));
     return FOCR_OK;
 }

@@ -69,3 +69,28 @@ def test_cli_text_csv_raw(tmp_path):
             k += 1
     r = subprocess.run(common + ["--raw", "-i"] + paths, capture_output=True, text=True)
     assert r.returncode == 101  # assert!(args.img.len() == 1), src/ncc.rs:834
+
+
+@pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")
+def test_cli_batched_pipeline_is_order_preserving(tmp_path):
+    """The decode/scan pipeline (batches, mixed page sizes, decode-ahead back-pressure) prints the same bytes
+    whatever the batch size; a missing image panics (exit 101) like image::open(..).unwrap(), src/ncc.rs:575."""
+    alphabet = ASCII95[1:40]
+    bank = Bank.rasterize(FONT, 13, 0, 0, alphabet=alphabet)
+    paths = []
+    for p in range(9):
+        pg = synth_page(bank, SYNTH_SEED_BASE + 900 + p, 280 + 24 * (p % 3), 120 + 15 * (p % 2))
+        paths.append(str(tmp_path / f"q{p}.pgm"))
+        save_pgm(paths[-1], pg)
+    cmd = [NCC, "-f", FONT, "-t", "13", "-a", alphabet, "--csv", "-i"] + paths
+    outs = []
+    for batch in ("256", "1", "2", "4"):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH=batch))
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert len(outs[0].splitlines()) > 200
+    assert all(o == outs[0] for o in outs[1:])
+    pages_seen = [int(l.split(",")[0]) for l in outs[0].splitlines()]
+    assert pages_seen == sorted(pages_seen) and set(pages_seen) == set(range(9))
+    r = subprocess.run(cmd + [str(tmp_path / "missing.pgm")], capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH="2"))
+    assert r.returncode == 101 and "cannot open image" in r.stderr
