@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
     ap.add_argument("--with-upload", action="store_true", help="also time steps that start from host pages (PCIe-inclusive rate, reported as e2e_*)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
+                         "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
+                         "overlap another's MFMA scan; 1 = strictly one batch at a time")
     args = ap.parse_args()
 
     # Exactly ONE line may reach stdout (the JSON).  RCCL prints a version banner to stdout at init, so park
@@ -97,32 +101,48 @@ def main():
         bank_file = "bank_dejavu13_ascii95_x2y2.bin"
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", bank_file))
     P = args.pages_per_gpu
-    if args.noise:
-        pages = np.random.default_rng(1234 + rank).integers(0, 256, (P, R_H, R_W), dtype=np.uint8)
-    else:
-        pages = synth_pages(bank, P, R_W, R_H, first=rank * P)  # every rank scans its own shard of the page set
-
-    sc = Scanner(local_rank)
-    sc.set_bank(bank)
-    # inputs resident in HBM before the timed region: pages go up as a torch tensor, then device->device ingest
-    d_pages = torch.from_numpy(pages).to(dev)
-    sc.alloc_pages(P, R_W, R_H)
-    sc.upload_pages_device(d_pages.data_ptr(), P, 0, invert=True)
-    sc.sync()
+    n_ctx = max(1, args.in_flight)
+    scs, pages = [], None
+    for j in range(n_ctx):  # every rank (and every context of it) scans its own shard of the page set
+        if args.noise:
+            pg = np.random.default_rng(1234 + rank * n_ctx + j).integers(0, 256, (P, R_H, R_W), dtype=np.uint8)
+        else:
+            pg = synth_pages(bank, P, R_W, R_H, first=(rank * n_ctx + j) * P)
+        if j == 0:
+            pages = pg
+        c_ = Scanner(local_rank)
+        c_.set_bank(bank)
+        # inputs resident in HBM before the timed region: pages go up as a torch tensor, then device->device ingest
+        d_pages = torch.from_numpy(pg).to(dev)
+        c_.alloc_pages(P, R_W, R_H)
+        c_.upload_pages_device(d_pages.data_ptr(), P, 0, invert=True)
+        c_.sync()
+        del d_pages
+        scs.append(c_)
+    sc = scs[0]
 
     class _DevBytes:  # zero-copy view of the library's device buffer for torch (no host round trip)
         def __init__(self, ptr, nbytes):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
-    pending = []  # the previous step's gather, still in flight on RCCL's stream while this step scans
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
 
-    def gather_lines():
+    pending = []  # earlier steps' gathers, still in flight on RCCL's stream while later steps scan
+    pool = ThreadPoolExecutor(max_workers=n_ctx)  # one host thread per context (ctypes calls release the GIL)
+    jobs = deque()  # (context index, future) of the steps in flight, oldest first
+
+    def gather_lines(c_):
         """RCCL gather of the post-processed characters (variable length, device resident) to rank 0.  Launched
-        asynchronously: it overlaps the next step's scan and is waited for one step later (and before the clock stops)."""
-        ptr, cnt = sc.device_chars()
+        asynchronously: it overlaps later steps' scans and is waited for a step later (and before the clock stops).
+        Only the main thread issues collectives, in step order, so every rank issues them in the same order."""
+        ptr, cnt = c_.device_chars()
         nbytes = cnt * HIT_DTYPE.itemsize
-        mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev) if nbytes else torch.zeros(0, dtype=torch.uint8, device=dev)
-        torch.cuda.current_stream().synchronize()  # `mine` was produced on the library's stream, already synced by process_hits
+        if nbytes:
+            mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev).clone()  # private copy: the context is reused next
+        else:
+            mine = torch.zeros(0, dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream().synchronize()
         pending.append(gather_chars(mine, rank, world, dev, async_op=True))
         n_prev = 0
         while len(pending) > 1:
@@ -137,40 +157,60 @@ def main():
             n_last = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
         return n_last
 
-    def step():
-        sc.scan(args.threshold, 1024, mode)
-        sc.process_hits(0.95, 5)
-        if use_dist:
-            return gather_lines()
-        return sc.total_chars()
+    def run_step(c_):  # one pass of the hot path over one resident batch (worker thread)
+        c_.scan(args.threshold, 1024, mode)
+        c_.process_hits(0.95, 5)
+        return c_.launches(), c_.timings(), c_.total_chars()
+
+    kern = {}
+    phase = {}
+    n_chars = 0
+    timed = False
+
+    def retire():
+        """Consume the oldest step in flight: its results stay on the device; with several ranks they are gathered."""
+        nonlocal n_chars
+        j, fut = jobs.popleft()
+        launches, timings, chars = fut.result()
+        if timed:
+            for li in launches:
+                k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
+                k["ms"] += li["ms"]
+                k["n"] += 1
+            for k_, v in timings.items():
+                phase[k_] = phase.get(k_, 0.0) + v
+        n_chars = (gather_lines(scs[j]) if use_dist else chars) or n_chars
+
+    def step(k):
+        if len(jobs) == n_ctx:  # context k % n_ctx is still busy with step k - n_ctx
+            retire()
+        jobs.append((k % n_ctx, pool.submit(run_step, scs[k % n_ctx])))
 
     def fence():
-        sc.sync()
+        while jobs:
+            retire()
+        for c_ in scs:
+            c_.sync()
         drain_gathers()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
+    timed = True
     t0 = time.perf_counter()
-    kern = {}
-    phase = {}
-    n_chars = 0
-    for _ in range(args.steps):
-        n_chars = step() or n_chars
-        for li in sc.launches():
-            k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
-            k["ms"] += li["ms"]
-            k["n"] += 1
-        for k_, v in sc.timings().items():
-            phase[k_] = phase.get(k_, 0.0) + v
+    for k in range(args.steps):
+        step(k)
+    while jobs:
+        retire()
     if use_dist:
         n_chars = drain_gathers() or n_chars
     fence()
     dt = time.perf_counter() - t0
+    timed = False
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,7 +225,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             sc.upload_pages(pages, 0, invert=True)
-            step()
+            run_step(sc)
         fence()
         e2e = total_px / (time.perf_counter() - t1) / 1e6
         # (2) double-buffered ingest: two contexts, pages in page-locked memory; while one context scans batch k
@@ -234,11 +274,12 @@ def main():
         "dtype": "i8",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[1]: 128 synthetic 608x720 pages per GPU, 95-glyph DejaVu Sans Mono 13px bank, "
+            "workload": (f"BASELINE configs[1]: batches of {P} synthetic 608x720 pages, 95-glyph DejaVu Sans Mono 13px bank, "
                          "--x-bits 2 --y-bits 0 (380 templates), threshold 0.8, cap 1024, + process_hits(0.95, 5)") if args.config == "c2"
-                        else (f"BASELINE configs[2] geometry: {P} synthetic 1200x1600 pages per GPU, 95-glyph bank, --x-bits 2 --y-bits 2 "
+                        else (f"BASELINE configs[2] geometry: batches of {P} synthetic 1200x1600 pages, 95-glyph bank, --x-bits 2 --y-bits 2 "
                               "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
             "pages_per_gpu": P,
+            "batches_in_flight": n_ctx,
             "templates": len(bank),
             "scan_mode": args.mode,
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
@@ -311,7 +352,9 @@ def main():
 
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    sc.close()
+    pool.shutdown()
+    for c_ in scs:
+        c_.close()
     if use_dist:
         dist.destroy_process_group()
 

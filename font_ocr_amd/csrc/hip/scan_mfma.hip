@@ -49,18 +49,22 @@ int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims
 // = 0 iff V = 0, because V/n >= 1/n is far above the rounding error of the division).
 // negL = -(floor(kq * sqrt(V)) - 2) with kq = kappa/sqrt(n) rounded toward -inf in f32: conservative
 // (f32 sqrt/convert/multiply errors are < 1 for |L| < 4e6; the -2 absorbs them).
-constexpr int STX = 64, STY = 32, SLDW = 21, SMAXROWS = STY + 31;
+constexpr int STX = 64, STY = 32, SLDW = 21;
+static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h - 1) * (SLDW * 4 + STX * 4 + STX * 2); }
 
-template <int NDW>
+template <int NDW, bool SMALLN>
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                     uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, float kq,
                                                     int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows,
                                                     uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
-    __shared__ uint32_t tile[SMAXROWS][SLDW];
-    __shared__ uint32_t H[SMAXROWS][STX];
-    __shared__ uint32_t H2[SMAXROWS][STX];
+    // dynamic LDS, sized for this class's n_h (stats_lds_bytes): ~21 KB at n_h = 15 -> 7 blocks per CU; the kernel
+    // lives on that occupancy (global-load latency, two barriers per tile)
+    extern __shared__ uint32_t stats_lds[];
     const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const uint32_t rows = STY + n_h - 1;
+    uint32_t (*tile)[SLDW] = reinterpret_cast<uint32_t (*)[SLDW]>(stats_lds);
+    uint32_t (*H2)[STX] = reinterpret_cast<uint32_t (*)[STX]>(stats_lds + rows * SLDW);
+    uint16_t (*H)[STX] = reinterpret_cast<uint16_t (*)[STX]>(stats_lds + rows * (SLDW + STX));  // row sums <= 16 * 255
     const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
     for (uint32_t i = threadIdx.x; i < rows * SLDW; i += 256) {
         uint32_t r = i / SLDW, cdw = i % SLDW;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 h = __builtin_amdgcn_udot4(w, 0x01010101u, h, false);
                 h2 = __builtin_amdgcn_udot4(w, w, h2, false);
             }
-            H[r][lane] = h;
+            H[r][lane] = (uint16_t)h;
             H2[r][lane] = h2;
         }
     }
@@ -100,27 +104,40 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
         s2 += H2[r0 + j][col];
     }
     const uint32_t n = n_w * n_h;
+    // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
+    const bool x_ok = x >= 1 && x + n_w <= r_w;
+    const uint32_t ya = y0 + r0;
+    int32_t *out_p = negL + ((size_t)page * Lrows + ya) * Lpitch + x;
+    // M-tile marks: one store per 16-lane group and window row, decided by ballot (blank paper is never scanned;
+    // the reference prunes it too, src/ncc.rs:280-301).  Row y of the image is tile row y - 1.
+    const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
+    const size_t live_i = ((size_t)page * n_rows + ya) * mtx + (x >> 4);  // entry of image row ya + 1
+#pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t y = y0 + r0 + k;
+        const uint32_t y = ya + k;
         if (y < Lrows) {
-            // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
-            const bool in_range = x >= 1 && y >= 1 && x + n_w <= r_w && y + n_h <= r_h;
-            const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;  // exact; > 0 <=> the reference's rnorm is finite
-            int32_t out = -REJECT;
-            if (in_range && V != 0) {
-                float Lf = __builtin_floorf(kq * __builtin_sqrtf((float)V)) - 2.0f;
-                Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-                out = -(int32_t)Lf;
+            // V = n*s2 - s*s, exact; V > 0 <=> the reference's rnorm is finite.  SMALLN (n <= 256): both products
+            // fit 32 bits (n*s2 <= n^2 * 255^2 < 2^32, s <= 255 n < 2^16).
+            bool nz;
+            float Vf;
+            if (SMALLN) {
+                const uint32_t V = n * s2 - s * s;
+                nz = V != 0;
+                Vf = (float)V;
+            } else {
+                const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;
+                nz = V != 0;
+                Vf = (float)V;
             }
-            // mark the 16-window M-tile as having something to scan (blank paper never does: the reference prunes
-            // it too, src/ncc.rs:280-301): one store per 16-lane group, decided by ballot
-            {
-                const uint64_t lm = __builtin_amdgcn_ballot_w64(out != -REJECT);
-                const uint32_t lane = threadIdx.x & 63;
-                if ((lane & 15) == 0 && ((lm >> lane) & 0xffffu) && y >= 1 && (y - 1) < n_rows && (x >> 4) < mtx)
-                    live[((size_t)page * n_rows + (y - 1)) * mtx + (x >> 4)] = 1;
-            }
-            negL[((size_t)page * Lrows + y) * Lpitch + x] = out;
+            // raw v_sqrt_f32 (1 ulp): with the conversion and the product the relative error stays < 2.5e-7, i.e.
+            // < 1 for |L| < 4e6; the -2 absorbs it
+            float Lf = __builtin_floorf(kq * __builtin_amdgcn_sqrtf(Vf)) - 2.0f;
+            Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+            const bool emit = x_ok && y >= 1 && y + n_h <= r_h && nz;
+            const int32_t out = emit ? -(int32_t)Lf : -REJECT;
+            const uint64_t lm = __builtin_amdgcn_ballot_w64(emit);
+            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
+            out_p[(size_t)k * Lpitch] = out;
         }
         if (k + 1 < PER) {  // slide down one row
             s += H[r0 + k + n_h][col] - H[r0 + k][col];
@@ -373,9 +390,13 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
     float kq = (float)kq_d;
     if ((double)kq > kq_d) kq = std::nextafterf(kq, -INFINITY);
     kq = std::nextafterf(kq, -INFINITY);
-    hipLaunchKernelGGL((stats_kernel<NDW>), grid, dim3(256), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
-                       (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
-                       n_rows);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
+                           n_rows);
+    };
+    if (sc.n_w * sc.n_h <= 256) launch(stats_kernel<NDW, true>);
+    else launch(stats_kernel<NDW, false>);
 }
 
 int launch_scan_mfma(focr_ctx *c, float threshold) {
