@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -279,7 +281,7 @@ int main(int argc, char **argv) {
     // Pages of one batch are grouped by size (one resident device batch per size).  Output is produced per page
     // and written in page order, so the bytes on stdout are those of the reference's sorted print (src/ncc.rs:845-877).
     const size_t N = args.img.size();
-    size_t kBatch = 256, kAhead = 3;
+    size_t kBatch = 256, kAhead = 5;  // decode-ahead in batches; must exceed the contexts in flight (<= 4)
     if (const char *e = getenv("FOCR_CLI_BATCH")) kBatch = std::max<size_t>(1, strtoul(e, nullptr, 10));
     struct Page {
         uint8_t *px = nullptr;
@@ -331,75 +333,96 @@ int main(int argc, char **argv) {
         die(msg);
     };
 
-    focr_ctx_t *ctx = nullptr;
-    if (focr_ctx_create(0, &ctx) != FOCR_OK) fatal(std::string("no usable GPU: ") + focr_last_error_global());
-#define CKF(expr)                                                                    \
-    do {                                                                             \
-        if ((expr) != FOCR_OK) fatal(std::string(#expr) + ": " + focr_last_error(ctx)); \
-    } while (0)
-    CKF(focr_bank_upload(ctx, bank.templates, bank.n_templates, bank.needles, bank.needles_len));
+    // FOCR_CLI_CONTEXTS=n (default 1): n device contexts take the batches alternately, each batch on its own host
+    // thread, so that one batch's upload / statistics / sort / verify overlap another's MFMA scan (the scheme of
+    // bench.py --in-flight 2).  Measured on image files it does not pay: this loop is bound by the pageable
+    // host<->device copies, not by the scan, hence the default.
+    size_t n_ctx = 1;
+    if (const char *e = getenv("FOCR_CLI_CONTEXTS")) n_ctx = std::min<size_t>(4, std::max<size_t>(1, strtoul(e, nullptr, 10)));
+    n_ctx = std::min(n_ctx, n_batches);
+    if (args.raw) n_ctx = 1;
+    std::vector<focr_ctx_t *> ctxs(n_ctx, nullptr);
+    for (size_t j = 0; j < n_ctx; j++) {
+        if (focr_ctx_create(0, &ctxs[j]) != FOCR_OK) fatal(std::string("no usable GPU: ") + focr_last_error_global());
+        if (focr_bank_upload(ctxs[j], bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
+            fatal(std::string("focr_bank_upload: ") + focr_last_error(ctxs[j]));
+    }
     const int mode = args.rust ? FOCR_SCAN_DIRECT : FOCR_SCAN_MFMA;
     clk.lap("ctx + bank");
 
     const size_t T = bank.n_templates;
-    std::string out;  // formatted output of the pages finished so far
-    double ms_wait = 0, ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
+    struct BatchOut {
+        std::string text, err, log;
+        double ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
+    };
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
-    for (size_t b = 0; b < n_batches; b++) {
+
+    // Everything the device does for one decoded batch; runs on a worker thread, touches only its own context.
+    auto process_batch = [&](size_t b, focr_ctx_t *ctx) -> BatchOut {
+        BatchOut r;
         const size_t p0 = b * kBatch, p1 = std::min(N, p0 + kBatch);
-        auto t0 = now();
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return left[b] == 0; });
-        }
-        ms_wait += since(t0);
+#define CKB(expr)                                                        \
+    do {                                                                 \
+        if ((expr) != FOCR_OK) {                                         \
+            r.err = std::string(#expr) + ": " + focr_last_error(ctx);    \
+            return r;                                                    \
+        }                                                                \
+    } while (0)
         std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
         for (size_t i = p0; i < p1; i++) {
-            if (!pages[i].err.empty()) fatal("cannot open image: " + pages[i].err);  // image::open(..).unwrap(), src/ncc.rs:575
+            if (!pages[i].err.empty()) {  // image::open(..).unwrap(), src/ncc.rs:575
+                r.err = "cannot open image: " + pages[i].err;
+                return r;
+            }
             groups[{pages[i].w, pages[i].h}].push_back(i);
         }
         std::vector<std::string> page_out(p1 - p0);
         for (auto &kv : groups) {
             const size_t w = kv.first.first, h = kv.first.second;
             const std::vector<size_t> &idx = kv.second;
+            auto t0 = now();
+            CKB(focr_pages_alloc(ctx, idx.size(), w, h));
+            for (size_t k = 0; k < idx.size(); k++) CKB(focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
+            r.ms_upload += since(t0);
             t0 = now();
-            CKF(focr_pages_alloc(ctx, idx.size(), w, h));
-            for (size_t k = 0; k < idx.size(); k++) CKF(focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
-            ms_upload += since(t0);
-            t0 = now();
-            CKF(focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
-            ms_scan += since(t0);
+            CKB(focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
+            r.ms_scan += since(t0);
             t0 = now();
             std::vector<uint32_t> counts(idx.size() * T);
-            CKF(focr_get_counts(ctx, counts.data()));
+            CKB(focr_get_counts(ctx, counts.data()));
             for (uint32_t cnt : counts)
-                if (cnt == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+                if (cnt == FOCR_MAX_MATCHES) r.log += "WARN got >= " + std::to_string(FOCR_MAX_MATCHES) + " matches\n";  // src/ncc.rs:395-397
             if (args.verbose) {
                 float ms[6];
                 focr_last_timings(ctx, ms);
-                fprintf(stderr, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5], focr_total_matches(ctx));
+                char line[160];
+                snprintf(line, sizeof line, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5],
+                         focr_total_matches(ctx));
+                r.log += line;
             }
-            if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order, then exit
+            if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order (exactly one image: src/ncc.rs:834)
                 std::vector<uint64_t> off(idx.size() * T + 1);
                 std::vector<focr_match_t> m(focr_total_matches(ctx));
-                CKF(focr_get_matches(ctx, off.data(), m.data()));
+                CKB(focr_get_matches(ctx, off.data(), m.data()));
                 for (size_t t = 0; t < T; t++) {
                     const focr_template_t &d = bank.templates[t];
                     for (uint64_t q = off[t]; q < off[t + 1]; q++) {
                         float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
-                        printf("%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x, m[q].y, d.n_w,
-                               d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str());
+                        char row[256];
+                        snprintf(row, sizeof row, "%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x,
+                                 m[q].y, d.n_w, d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(),
+                                 f32s(d.off_y).c_str());
+                        r.text += row;
                     }
                 }
-                stop_pool();
-                return 0;
+                return r;
             }
-            CKF(focr_process_hits(ctx, args.anchor_threshold, args.overlap));
+            CKB(focr_process_hits(ctx, args.anchor_threshold, args.overlap));
             std::vector<uint64_t> page_off(idx.size() + 1), line_off(focr_total_lines(ctx) + 1);
             std::vector<focr_hit_t> chars(focr_total_chars(ctx));
-            CKF(focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
-            ms_post += since(t0);
+            CKB(focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
+            r.ms_post += since(t0);
             t0 = now();
             for (size_t k = 0; k < idx.size(); k++) {  // output, src/ncc.rs:849-877
                 std::string &s = page_out[idx[k] - p0];
@@ -419,30 +442,61 @@ int main(int argc, char **argv) {
                     if (!args.csv) s += '\n';
                 }
             }
-            ms_format += since(t0);
+            r.ms_format += since(t0);
         }
+#undef CKB
         for (size_t i = p0; i < p1; i++) {
-            out += page_out[i - p0];
+            r.text += page_out[i - p0];
             free(pages[i].px);
             pages[i].px = nullptr;
         }
-        if (out.size() > (1u << 20) || b + 1 == n_batches) {
+        return r;
+    };
+
+    double ms_wait = 0, ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
+    std::deque<std::future<BatchOut>> inflight;  // oldest first: results are written in batch order
+    std::string out;
+    size_t retired = 0;
+    auto retire = [&]() {
+        BatchOut r = inflight.front().get();
+        inflight.pop_front();
+        fputs(r.log.c_str(), stderr);
+        if (!r.err.empty()) {
+            for (auto &f : inflight) f.wait();
+            fatal(r.err);
+        }
+        ms_upload += r.ms_upload, ms_scan += r.ms_scan, ms_post += r.ms_post, ms_format += r.ms_format;
+        out += r.text;
+        retired++;
+        if (out.size() > (1u << 20) || retired == n_batches) {
             fwrite(out.data(), 1, out.size(), stdout);
             out.clear();
         }
         {
             std::lock_guard<std::mutex> lk(mu);
-            consumed = b + 1;
+            consumed = retired;
         }
         cv.notify_all();
+    };
+    for (size_t b = 0; b < n_batches; b++) {
+        if (inflight.size() == n_ctx) retire();  // context b % n_ctx is the one that ran batch b - n_ctx
+        auto t0 = now();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return left[b] == 0; });  // b <= retired + n_ctx - 1 < consumed + kAhead: decoders may reach it
+        }
+        ms_wait += since(t0);
+        inflight.push_back(std::async(std::launch::async, process_batch, b, ctxs[b % n_ctx]));
     }
+    while (!inflight.empty()) retire();
     stop_pool();
     if (args.verbose)
-        fprintf(stderr, "pipeline: %zu batch(es) of <= %zu pages; main thread waited %.2f ms for decode, upload %.2f ms, scan %.2f ms, "
-                        "counts+process_hits+fetch %.2f ms, format %.2f ms\n", n_batches, kBatch, ms_wait, ms_upload, ms_scan, ms_post, ms_format);
+        fprintf(stderr, "pipeline: %zu batch(es) of <= %zu pages on %zu context(s); main thread waited %.2f ms for decode; per-batch sums: "
+                        "upload %.2f ms, scan %.2f ms, counts+process_hits+fetch %.2f ms, format %.2f ms\n",
+                n_batches, kBatch, n_ctx, ms_wait, ms_upload, ms_scan, ms_post, ms_format);
     clk.lap("pages");
     fflush(stdout);
-    focr_ctx_destroy(ctx);
+    for (focr_ctx_t *c : ctxs) focr_ctx_destroy(c);
     focr_bank_free(&bank);
     clk.lap("teardown");
     if (args.verbose)
