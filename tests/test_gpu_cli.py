@@ -84,8 +84,8 @@ def test_cli_batched_pipeline_is_order_preserving(tmp_path):
         save_pgm(paths[-1], pg)
     cmd = [NCC, "-f", FONT, "-t", "13", "-a", alphabet, "--csv", "-i"] + paths
     outs = []
-    for batch in ("256", "1", "2", "4"):
-        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH=batch))
+    for batch, contexts in (("256", "1"), ("1", "1"), ("2", "1"), ("4", "1"), ("2", "2"), ("1", "3")):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH=batch, FOCR_CLI_CONTEXTS=contexts))
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout)
     assert len(outs[0].splitlines()) > 200
