@@ -247,6 +247,12 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     delete c;
 }
 
+int focr_ctx_set_scan_share(focr_ctx_t *c, unsigned eighths) {
+    if (!c || eighths < 1 || eighths > 8) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_scan_share: eighths must be 1..8");
+    c->scan_share = eighths;
+    return FOCR_OK;
+}
+
 int focr_sync(focr_ctx_t *c) {
     if (!c) return FOCR_ERR_INVALID;
     FOCR_HIP(c, hipSetDevice(c->device));

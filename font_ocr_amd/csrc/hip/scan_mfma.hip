@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "mfma_common.h"
 
@@ -399,6 +400,15 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
     else launch(stats_kernel<NDW, false>);
 }
 
+// Process-wide hand-over of the scan kernel between contexts of one device (events are never destroyed).
+struct ScanTurns {
+    std::mutex mu;
+    hipEvent_t ev[8];
+    unsigned n = 0;
+    bool init = false;
+};
+static ScanTurns scan_turns[64];
+
 int launch_scan_mfma(focr_ctx *c, float threshold) {
     const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
     const uint32_t Lpitch = (uint32_t)((c->r_w + 63) / 64 * 64 + 64), Lrows = (uint32_t)((c->r_h + 7) / 8 * 8 + 8);
@@ -481,8 +491,20 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             FOCR_HIP(c, hipGetLastError());
         }
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
-        // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget)
+        // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget).
+        // With several contexts in flight on one GPU the persistent scan kernels take turns: each context's launches
+        // wait (on the device, hipStreamWaitEvent) for the previous context's to finish.  Two of them sharing the
+        // MFMA pipes finish no sooner than one after the other; in turn each runs at its full rate while the other
+        // contexts' small kernels use the CUs left free by focr_ctx_set_scan_share.
         if (c->supers.size() > 40) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many super-classes");
+        {
+        ScanTurns &tn = scan_turns[(unsigned)c->device % 64];
+        std::lock_guard<std::mutex> turn(tn.mu);  // held only while enqueueing
+        if (!tn.init) {
+            for (hipEvent_t &e : tn.ev) FOCR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            tn.init = true;
+        }
+        if (tn.n) FOCR_HIP(c, hipStreamWaitEvent(c->stream, tn.ev[(tn.n - 1) % 8], 0));
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
@@ -528,9 +550,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.n_tiles16 = t1 - t0;
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
-                if ((rc = dispatch_mfma_v2(c, L, (unsigned)prop.multiProcessorCount))) return rc;
+                const unsigned cus = std::max(1u, (unsigned)prop.multiProcessorCount * c->scan_share / 8);
+                if ((rc = dispatch_mfma_v2(c, L, cus))) return rc;
                 t0 = t1;
             }
+        }
+        FOCR_HIP(c, hipEventRecord(tn.ev[tn.n % 8], c->stream));
+        tn.n++;
         }
         // tall classes: exact scan straight into the candidate list
         for (size_t k = 0; k < c->classes.size(); k++) {
