@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
     ap.add_argument("--with-upload", action="store_true", help="also time steps that start from host pages (PCIe-inclusive rate, reported as e2e_*)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
-    ap.add_argument("--scan-share", type=int, default=0,
-                    help="eighths of the CUs the persistent scan kernel occupies (0 = auto: 8 with one batch in flight, else 7)")
+    ap.add_argument("--scan-cus", type=int, default=-1,
+                    help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
+                         "of them (one CU per shader engine left to the other contexts' small kernels)")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
                          "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
@@ -104,6 +105,8 @@ def main():
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", bank_file))
     P = args.pages_per_gpu
     n_ctx = max(1, args.in_flight)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_ctx == 1 else n_cus - n_cus // 8)
     scs, pages = [], None
     for j in range(n_ctx):  # every rank (and every context of it) scans its own shard of the page set
         if args.noise:
@@ -114,7 +117,7 @@ def main():
             pages = pg
         c_ = Scanner(local_rank)
         c_.set_bank(bank)
-        c_.set_scan_share(args.scan_share or (8 if n_ctx == 1 else 7))
+        c_.set_scan_cus(scan_cus)
         # inputs resident in HBM before the timed region: pages go up as a torch tensor, then device->device ingest
         d_pages = torch.from_numpy(pg).to(dev)
         c_.alloc_pages(P, R_W, R_H)
@@ -267,7 +270,7 @@ def main():
     # region, reported beside the in-flight figure so that both ways of reading "kernel duration" are on the table
     iso = {}
     if rank == 0 and n_ctx > 1:
-        sc.set_scan_share(8)
+        sc.set_scan_cus(0)
         for i in range(5):
             run_step(sc)
             if i >= 2:
@@ -275,7 +278,7 @@ def main():
                     k = iso.setdefault(li["name"], dict(ms=0.0, n=0))
                     k["ms"] += li["ms"]
                     k["n"] += 1
-        sc.set_scan_share(args.scan_share or 7)
+        sc.set_scan_cus(scan_cus)
 
     out = {
         "metric": "Mpixels/s scanned (95-glyph x --x-bits=2 bank)",
@@ -295,9 +298,10 @@ def main():
                          "--x-bits 2 --y-bits 0 (380 templates), threshold 0.8, cap 1024, + process_hits(0.95, 5)") if args.config == "c2"
                         else (f"BASELINE configs[2] geometry: batches of {P} synthetic 1200x1600 pages, 95-glyph bank, --x-bits 2 --y-bits 2 "
                               "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
-            "pages_per_gpu": P,
+            "pages_per_batch": P,
+            "resident_pages_per_gpu": P * n_ctx,
             "batches_in_flight": n_ctx,
-            "scan_cu_share": f"{args.scan_share or (8 if n_ctx == 1 else 7)}/8",
+            "scan_cus": scan_cus or n_cus,
             "templates": len(bank),
             "scan_mode": args.mode,
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",

@@ -102,7 +102,7 @@ HIP_SYMBOLS = {
     "focr_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_last_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_sync": (C.c_int, [C.c_void_p]),
-    "focr_ctx_set_scan_share": (C.c_int, [C.c_void_p, C.c_uint]),
+    "focr_ctx_set_scan_cus": (C.c_int, [C.c_void_p, C.c_uint]),
     "focr_last_launches": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_debug_rnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -100,7 +100,7 @@ struct focr_ctx {
     // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded
     size_t n_pages = 0, r_w = 0, r_h = 0, pitch = 0, rows_alloc = 0;
     size_t pages_capacity = 0;  // pages d_pages was allocated for (>= n_pages)
-    unsigned scan_share = 8;    // eighths of the CUs the persistent scan kernel may occupy (focr_ctx_set_scan_share)
+    unsigned scan_cus = 0;      // CUs the persistent scan kernel may occupy, 0 = all (focr_ctx_set_scan_cus)
     uint8_t *d_pages = nullptr;
     uint8_t *d_stage = nullptr;  // device staging for uploads
     size_t stage_bytes = 0;

@@ -247,9 +247,9 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     delete c;
 }
 
-int focr_ctx_set_scan_share(focr_ctx_t *c, unsigned eighths) {
-    if (!c || eighths < 1 || eighths > 8) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_scan_share: eighths must be 1..8");
-    c->scan_share = eighths;
+int focr_ctx_set_scan_cus(focr_ctx_t *c, unsigned max_cus) {
+    if (!c) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_scan_cus: null context");
+    c->scan_cus = max_cus;
     return FOCR_OK;
 }
 

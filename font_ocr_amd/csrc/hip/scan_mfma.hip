@@ -495,7 +495,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         // With several contexts in flight on one GPU the persistent scan kernels take turns: each context's launches
         // wait (on the device, hipStreamWaitEvent) for the previous context's to finish.  Two of them sharing the
         // MFMA pipes finish no sooner than one after the other; in turn each runs at its full rate while the other
-        // contexts' small kernels use the CUs left free by focr_ctx_set_scan_share.
+        // contexts' small kernels use the CUs left free by focr_ctx_set_scan_cus.
         if (c->supers.size() > 40) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many super-classes");
         {
         ScanTurns &tn = scan_turns[(unsigned)c->device % 64];
@@ -504,7 +504,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             for (hipEvent_t &e : tn.ev) FOCR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             tn.init = true;
         }
-        if (tn.n) FOCR_HIP(c, hipStreamWaitEvent(c->stream, tn.ev[(tn.n - 1) % 8], 0));
+        static const bool no_turns = getenv("FOCR_NO_SCAN_TURNS") != nullptr;  // A/B experiments only
+        if (tn.n && !no_turns) FOCR_HIP(c, hipStreamWaitEvent(c->stream, tn.ev[(tn.n - 1) % 8], 0));
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
@@ -550,7 +551,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.n_tiles16 = t1 - t0;
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
-                const unsigned cus = std::max(1u, (unsigned)prop.multiProcessorCount * c->scan_share / 8);
+                const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
                 if ((rc = dispatch_mfma_v2(c, L, cus))) return rc;
                 t0 = t1;
             }

@@ -160,9 +160,9 @@ class Scanner:
     def scan(self, threshold=0.8, cap=MAX_MATCHES, mode=SCAN_MFMA):
         self._ck(self._lib.focr_scan(self._h, float(threshold), int(cap), int(mode)))
 
-    def set_scan_share(self, eighths):
-        """Eighths of the CUs the persistent scan kernel may occupy (8 = all; 7 with several contexts in flight)."""
-        self._ck(self._lib.focr_ctx_set_scan_share(self._h, int(eighths)))
+    def set_scan_cus(self, max_cus):
+        """Upper bound on the CUs the persistent scan kernel occupies (0 = all)."""
+        self._ck(self._lib.focr_ctx_set_scan_cus(self._h, int(max_cus)))
 
     def sync(self):
         self._ck(self._lib.focr_sync(self._h))

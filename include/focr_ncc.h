@@ -192,13 +192,13 @@ int focr_last_timings(focr_ctx_t *ctx, float ms[6]);
 int focr_last_counters(focr_ctx_t *ctx, uint64_t c[4]);
 int focr_sync(focr_ctx_t *ctx);
 
-/* Share of the chip the persistent MFMA scan kernel may occupy, in eighths of
- * the compute units (1..8, default 8 = all).  With several contexts in flight
- * on one GPU (one host thread each, batches taken round-robin) 7 is the
- * measured optimum: the CUs left free let the other contexts' statistics /
- * sort / verify / ordering kernels run beside the scan instead of queueing
- * behind it. */
-int focr_ctx_set_scan_share(focr_ctx_t *ctx, unsigned eighths);
+/* Upper bound on the compute units the persistent MFMA scan kernel occupies
+ * (one workgroup per CU); 0 = all of them (default).  With several contexts in
+ * flight on one GPU (one host thread each, batches taken round-robin) leaving
+ * some CUs free lets the other contexts' statistics / sort / verify / ordering
+ * kernels run beside the scan instead of queueing behind it (DESIGN.md
+ * section 5). */
+int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
 
 /* Per-launch record of the scan kernels of the last focr_scan (one entry per
  * (size class, bank chunk) launch), timed with HIP events on the stream the

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--pages", type=int, default=128)
-    ap.add_argument("--share", type=int, default=8, help="eighths of the CUs for the scan kernel")
+    ap.add_argument("--cus", type=int, default=0, help="CUs for the scan kernel (0 = all)")
     a = ap.parse_args()
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
     pages = synth_pages(bank, a.pages, 608, 720)
@@ -33,7 +33,7 @@ def main():
     for _ in range(a.threads):
         sc = Scanner(0)
         sc.set_bank(bank)
-        sc.set_scan_share(a.share)
+        sc.set_scan_cus(a.cus)
         sc.set_pages(pages)
         for _ in range(2):
             sc.scan(0.8, 1024, SCAN_MFMA)
