@@ -234,36 +234,38 @@ def main():
             run_step(sc)
         fence()
         e2e = total_px / (time.perf_counter() - t1) / 1e6
-        # (2) double-buffered ingest: two contexts, pages in page-locked memory; while one context scans batch k
-        #     the other's stream DMAs batch k+1 (focr_pages_upload returns as soon as the copy is queued)
+        # (2) pipelined ingest: every step starts from page-locked host memory; the same contexts / host threads as
+        #     the headline run, each uploading its batch (one asynchronous DMA + inversion kernel on its stream)
+        #     before scanning it, so batch k+1's copy runs under batch k's scan
         from font_ocr_amd.searcher import PinnedPages
 
-        pin = PinnedPages(P, R_H, R_W)
-        pin.array[:] = pages
-        sc2 = Scanner(local_rank)
-        sc2.set_bank(bank)
-        sc2.alloc_pages(P, R_W, R_H)
-        ctxs = [sc, sc2]
+        pins = []
+        for j in range(n_ctx):
+            pin = PinnedPages(P, R_H, R_W)
+            pin.array[:] = pages
+            pins.append(pin)
+
+        def run_step_upload(j):
+            scs[j].upload_pages(pins[j].array, 0, invert=True)
+            return run_step(scs[j])
 
         def pipe_steps(n):
-            ctxs[0].upload_pages(pin.array, 0, invert=True)
+            futs = deque()
             for k in range(n):
-                cur, nxt = ctxs[k % 2], ctxs[(k + 1) % 2]
-                if k + 1 < n:
-                    nxt.upload_pages(pin.array, 0, invert=True)  # queued on nxt's stream, overlaps cur's scan
-                cur.scan(args.threshold, 1024, mode)
-                cur.process_hits(0.95, 5)
-            for c_ in ctxs:
-                c_.sync()
+                if len(futs) == n_ctx:
+                    futs.popleft().result()
+                futs.append(pool.submit(run_step_upload, k % n_ctx))
+            while futs:
+                futs.popleft().result()
 
-        pipe_steps(2)  # warm the second context's buffers
+        pipe_steps(n_ctx)
         fence()
         t1 = time.perf_counter()
         pipe_steps(args.steps)
         fence()
         e2e_pipe = total_px / (time.perf_counter() - t1) / 1e6
-        sc2.close()
-        pin.close()
+        for pin in pins:
+            pin.close()
     counters = sc.counters()
 
     # the dominant kernel alone on the chip (no other batch in flight, all CUs): a short extra leg outside the timed
@@ -309,7 +311,7 @@ def main():
     }
     if e2e is not None:
         out["e2e_value_incl_h2d"] = round(e2e, 2)
-        out["e2e_value_incl_h2d_double_buffered"] = round(e2e_pipe, 2)
+        out["e2e_value_incl_h2d_pipelined"] = round(e2e_pipe, 2)
     if args.noise:
         out["data"] = "uniform random noise pages (worst case, no hits)"
     if rank == 0:
@@ -355,9 +357,11 @@ def main():
         S = args.cpu_sample_pages or min(P, 4 * threads)
         inv = (255 - pages[:S]).astype(np.uint8)
         use_ref = O.have_ref()
+        passes = 2  # ~15 s of CPU work on the GPU box's 32 threads
         t0 = time.perf_counter()
-        total, _, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
-        cdt = time.perf_counter() - t0
+        for _ in range(passes):
+            total, _, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
+        cdt = (time.perf_counter() - t0) / passes
         t0 = time.perf_counter()
         O.scan_pages_mt(inv[:2], bank, args.threshold, 1024, use_ref=use_ref, threads=1)  # single-core figure, 2 pages
         cdt1 = time.perf_counter() - t0
@@ -366,8 +370,8 @@ def main():
             "unit": "Mpx/s",
             "cores": threads,
             "kind": "reference" if use_ref else "port",
-            "sample": f"{S} of the same synthetic pages x {len(bank)} templates, one page per thread "
-                      f"(window tables + kernel calls as src/ncc.rs:231-404), {cdt:.1f} s wall, {int(total)} raw hits",
+            "sample": f"{S} of the same synthetic pages x {len(bank)} templates, {passes} passes, one page per thread "
+                      f"(window tables + kernel calls as src/ncc.rs:231-404), {cdt * passes:.1f} s wall, {int(total)} raw hits per pass",
             "value_1_core": round(2 * R_W * R_H / cdt1 / 1e6, 4),
         }
 
