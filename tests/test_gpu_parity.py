@@ -447,3 +447,41 @@ def test_pinned_async_upload_and_second_context(bank_x2):
             c.close()
         for p in pins:
             p.close()
+
+
+def test_three_contexts_on_three_threads(bank_x2):
+    """Batches in flight (bench.py --in-flight 3): three contexts driven concurrently from three host threads, scan
+    kernel capped to 7/8 of the CUs, taking turns on the device — every context still returns the oracle's lists."""
+    import threading
+
+    n_ctx, rounds = 3, 4
+    pages = [[np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 800 + 10 * j + 2 * r + p, 300, 100) for p in range(2)])
+              for r in range(rounds)] for j in range(n_ctx)]
+    want = [[_oracle_lists(pg, bank_x2, 0.8, 1024) for pg in pages[j]] for j in range(n_ctx)]
+    got = [[None] * rounds for _ in range(n_ctx)]
+    errs = []
+
+    def work(j):
+        try:
+            sc = Scanner(0)
+            sc.set_bank(bank_x2)
+            sc.set_scan_cus(224)
+            for r in range(rounds):
+                sc.set_pages(pages[j][r])
+                sc.scan(0.8, 1024, SCAN_MFMA)
+                sc.process_hits(0.95, 5)
+                offsets, m = sc.matches()
+                got[j][r] = _csr_to_lists(offsets, m, 2, len(bank_x2))
+            sc.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(n_ctx)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for j in range(n_ctx):
+        for r in range(rounds):
+            _assert_same(got[j][r], want[j][r], f"context {j} round {r}")
