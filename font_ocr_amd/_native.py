@@ -117,6 +117,7 @@ HOST_SYMBOLS = {
     "focr_synth_page": (C.c_size_t, [C.POINTER(BankStruct), C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_size_t]),
     "focr_format_f32": (C.c_size_t, [C.c_float, C.c_char_p, C.c_size_t]),
+    "focr_line_text": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_char_p, C.c_size_t]),
 }
 
 RASTER_SYMBOLS = {

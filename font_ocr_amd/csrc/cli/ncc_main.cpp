@@ -47,6 +47,7 @@ struct Args {
     std::string box_size = "alphabet";
     uint32_t x_padding = 0, y_padding = 0;
     bool save_letters = false, rust = false, verbose = false, csv = false, raw = false;
+    bool spaces = false;  // extension: fill gaps between characters with blanks (the reference does not, README.md:46)
 };
 
 [[noreturn]] void usage_error(const std::string &msg) {
@@ -74,6 +75,7 @@ void print_help() {
          "  -v, --verbose                              \n"
          "      --csv                                  \n"
          "      --raw                                  \n"
+         "      --spaces                               [extension] print blanks for gaps of whole advances\n"
          "  -h, --help                                 Print help\n"
          "  -V, --version                              Print version");
 }
@@ -139,6 +141,7 @@ Args parse_args(int argc, char **argv) {
         else if (k == "-v" || k == "--verbose") a.verbose = true;
         else if (k == "--csv") a.csv = true;
         else if (k == "--raw") a.raw = true;
+        else if (k == "--spaces") a.spaces = true;
         else if (k == "-h" || k == "--help") {
             print_help();
             exit(0);
@@ -427,19 +430,27 @@ int main(int argc, char **argv) {
             for (size_t k = 0; k < idx.size(); k++) {  // output, src/ncc.rs:849-877
                 std::string &s = page_out[idx[k] - p0];
                 for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++) {
+                    if (!args.csv) {
+                        const size_t nq = line_off[l + 1] - line_off[l];
+                        std::string line(4 * nq + (args.spaces ? 4096 : 0) + 1, '\0');
+                        size_t need = focr_line_text(chars.data() + line_off[l], nq, bank.advance_px, args.spaces, &line[0], line.size());
+                        if (need + 1 > line.size()) {  // a very wide gap: size exactly and redo
+                            line.assign(need + 1, '\0');
+                            need = focr_line_text(chars.data() + line_off[l], nq, bank.advance_px, args.spaces, &line[0], line.size());
+                        }
+                        line.resize(need);
+                        s += line;
+                        s += '\n';
+                        continue;
+                    }
                     for (uint64_t q = line_off[l]; q < line_off[l + 1]; q++) {
                         const focr_hit_t &c = chars[q];
-                        if (args.csv) {
-                            float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
-                            char row[160];
-                            snprintf(row, sizeof row, "%zu,%u,%s,%s,%u,%u,%u,%u\n", idx[k], c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x,
-                                     c.y, c.w, c.h);
-                            s += row;
-                        } else {
-                            s += utf8_encode(c.letter);
-                        }
+                        float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
+                        char row[160];
+                        snprintf(row, sizeof row, "%zu,%u,%s,%s,%u,%u,%u,%u\n", idx[k], c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x,
+                                 c.y, c.w, c.h);
+                        s += row;
                     }
-                    if (!args.csv) s += '\n';
                 }
             }
             r.ms_format += since(t0);

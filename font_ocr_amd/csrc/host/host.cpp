@@ -344,6 +344,39 @@ int focr_image_load_luma8(const char *path, uint8_t **px, size_t *w, size_t *h, 
     return fail(err, errlen, "unsupported image format (pnm and png only, Cargo.toml:10)");
 }
 
+size_t focr_line_text(const focr_hit_t *chars, size_t n, float advance_px, int spaces, char *out, size_t cap) {
+    size_t need = 0;
+    auto put = [&](char ch) {
+        if (out && need + 1 < cap) out[need] = ch;
+        need++;
+    };
+    for (size_t i = 0; i < n; i++) {
+        if (spaces && i > 0 && advance_px > 0.f) {
+            const float dx = (float)chars[i].x - (float)chars[i - 1].x;
+            const long cells = std::lround(dx / advance_px);
+            for (long k = 1; k < cells; k++) put(' ');
+        }
+        const uint32_t cp = chars[i].letter;
+        if (cp < 0x80) {
+            put((char)cp);
+        } else if (cp < 0x800) {
+            put((char)(0xc0 | (cp >> 6)));
+            put((char)(0x80 | (cp & 0x3f)));
+        } else if (cp < 0x10000) {
+            put((char)(0xe0 | (cp >> 12)));
+            put((char)(0x80 | ((cp >> 6) & 0x3f)));
+            put((char)(0x80 | (cp & 0x3f)));
+        } else {
+            put((char)(0xf0 | (cp >> 18)));
+            put((char)(0x80 | ((cp >> 12) & 0x3f)));
+            put((char)(0x80 | ((cp >> 6) & 0x3f)));
+            put((char)(0x80 | (cp & 0x3f)));
+        }
+    }
+    if (out && cap) out[std::min(need, cap - 1)] = 0;
+    return need;
+}
+
 int focr_image_save_pgm(const char *path, const uint8_t *px, size_t w, size_t h) {
     FILE *f = fopen(path, "wb");
     if (!f) return 1;

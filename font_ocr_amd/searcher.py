@@ -241,6 +241,14 @@ class Scanner:
         return out
 
 
-def text_of(lines):
-    """Default `ncc` output of one page: letters of each line concatenated (src/ncc.rs:869-876)."""
-    return "\n".join("".join(chr(int(c)) for c in line["letter"]) for line in lines)
+def text_of(lines, advance_px=None):
+    """Default `ncc` output of one page: letters of each line concatenated (src/ncc.rs:869-876).  With advance_px
+    (extension): blanks are inserted where consecutive origins are more than one advance apart."""
+    host = N.host()
+    out = []
+    for line in lines:
+        line = np.ascontiguousarray(line, HIT_DTYPE)
+        buf = C.create_string_buffer(8 * len(line) * 4 + 16)
+        host.focr_line_text(_ptr(line), len(line), float(advance_px or 0.0), int(advance_px is not None), buf, len(buf))
+        out.append(buf.value.decode("utf-8"))
+    return "\n".join(out)

@@ -53,6 +53,17 @@ int focr_image_load_luma8(const char *path, uint8_t **px, size_t *w, size_t *h, 
                           size_t errlen);
 int focr_image_save_pgm(const char *path, const uint8_t *px, size_t w, size_t h);
 
+/* Text of one output line as `ncc` prints it (src/ncc.rs:869-876): the letters
+ * of the line's characters concatenated, UTF-8, no terminator written beyond a
+ * NUL when it fits.  spaces != 0 is an EXTENSION (the reference does not detect
+ * spaces, README.md:46): the gap between the
+ * origins of consecutive characters is filled with round(dx / advance_px) - 1
+ * blanks, which is exact for a fixed-pitch font rendered with the `alphabet`
+ * or `font` box.  Returns the number of bytes the text needs (may exceed cap;
+ * at most cap - 1 bytes are written). */
+size_t focr_line_text(const focr_hit_t *chars, size_t n, float advance_px, int spaces, char *out,
+                      size_t cap);
+
 /* Synthetic page: white background, black
  * anti-aliased text composited from the bank itself.  Left/right margin 45 px,
  * first line box at y = 39, line advance = box height, pen advance =

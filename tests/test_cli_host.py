@@ -82,3 +82,28 @@ def test_pnm_and_png_decode(tmp_path):
     assert np.array_equal(load_image(tmp_path / "d.png"), img)
     with pytest.raises(OSError):
         load_image(tmp_path / "missing.png")
+
+
+def test_line_text_and_space_extension():
+    """focr_line_text: the reference's concatenation (src/ncc.rs:869-876) and the opt-in gap -> blanks extension."""
+    import ctypes as C
+
+    from font_ocr_amd import _native as N
+    from font_ocr_amd.bank import HIT_DTYPE
+    from font_ocr_amd.searcher import text_of
+
+    adv = 7.8267
+    cells = [0, 1, 2, 4, 5, 9, 10]  # one blank after the third letter, three after the fifth
+    line = np.zeros(len(cells), HIT_DTYPE)
+    line["x"] = [int(45 + c * adv) for c in cells]  # origins are floor(pen), as synth pages / real scans give them
+    line["letter"] = [ord(ch) for ch in "abcd"] + [0xE9, 0x20AC, 0x1F600]  # 2-, 3- and 4-byte UTF-8 too
+    assert text_of([line]) == "abcdé€\U0001F600"
+    assert text_of([line], advance_px=adv) == "abc dé   €\U0001F600"
+    assert text_of([line[:0]], advance_px=adv) == ""
+    # size query + truncation contract
+    host = N.host()
+    need = host.focr_line_text(line.ctypes.data_as(C.c_void_p), len(line), adv, 1, None, 0)
+    assert need == len("abc dé   €\U0001F600".encode())
+    buf = C.create_string_buffer(6)
+    assert host.focr_line_text(line.ctypes.data_as(C.c_void_p), len(line), adv, 1, buf, 6) == need
+    assert buf.value == b"abc d"

@@ -94,3 +94,34 @@ def test_cli_batched_pipeline_is_order_preserving(tmp_path):
     assert pages_seen == sorted(pages_seen) and set(pages_seen) == set(range(9))
     r = subprocess.run(cmd + [str(tmp_path / "missing.pgm")], capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH="2"))
     assert r.returncode == 101 and "cannot open image" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")
+def test_cli_spaces_extension(tmp_path):
+    """--spaces (extension): blanks for gaps of whole advances; off by default as in the reference."""
+    alphabet = ASCII95[33:59]  # A..Z
+    bank = Bank.rasterize(FONT, 13, 0, 0, alphabet=alphabet)
+    n_w, n_h = int(bank.templates[0]["n_w"]), int(bank.templates[0]["n_h"])
+    rng = np.random.default_rng(5)
+    ink = np.zeros((120, 330), np.uint32)
+    want = []
+    for li in range(3):
+        cells = sorted(rng.choice(30, size=18, replace=False).tolist())
+        text, prev = "", None
+        for c in cells:
+            t = int(rng.integers(0, len(alphabet)))
+            x, y = 40 + 8 * c, 20 + 30 * li
+            ink[y:y + n_h, x:x + n_w] += bank.needle(t)
+            text += ("" if prev is None else " " * (c - prev - 1)) + alphabet[t]
+            prev = c
+        want.append(text)
+    page = (255 - np.minimum(ink, 255)).astype(np.uint8)
+    path = str(tmp_path / "gaps.pgm")
+    save_pgm(path, page)
+    cmd = [NCC, "-f", FONT, "-t", "13", "-a", alphabet, "-i", path]
+    r = subprocess.run(cmd + ["--spaces"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == want
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == [w.replace(" ", "") for w in want]
