@@ -47,6 +47,7 @@ struct Args {
     std::string box_size = "alphabet";
     uint32_t x_padding = 0, y_padding = 0;
     bool save_letters = false, rust = false, verbose = false, csv = false, raw = false;
+    bool allow_wide = false;  // extension: templates 17..32 px wide instead of the reference's panic (src/ncc.rs:392)
     bool spaces = false;  // extension: fill gaps between characters with blanks (the reference does not, README.md:46)
 };
 
@@ -76,6 +77,7 @@ void print_help() {
          "      --csv                                  \n"
          "      --raw                                  \n"
          "      --spaces                               [extension] print blanks for gaps of whole advances\n"
+         "      --allow-wide                           [extension] accept templates 17..32 px wide\n"
          "  -h, --help                                 Print help\n"
          "  -V, --version                              Print version");
 }
@@ -142,6 +144,7 @@ Args parse_args(int argc, char **argv) {
         else if (k == "--csv") a.csv = true;
         else if (k == "--raw") a.raw = true;
         else if (k == "--spaces") a.spaces = true;
+        else if (k == "--allow-wide") a.allow_wide = true;
         else if (k == "-h" || k == "--help") {
             print_help();
             exit(0);
@@ -267,7 +270,7 @@ int main(int argc, char **argv) {
                 alphabet.size(), 1u << args.x_bits, 1u << args.y_bits, f32s(bank.advance_px).c_str());
     }
     for (size_t t = 0; t < bank.n_templates; t++)
-        if (bank.templates[t].n_w > 16) die("not handled");  // src/ncc.rs:392
+        if (bank.templates[t].n_w > 16 && !args.allow_wide) die("not handled");  // src/ncc.rs:392
     if (args.save_letters) {
         mkdir("letters", 0777);
         for (size_t t = 0; t < bank.n_templates; t++) {

@@ -18,9 +18,9 @@ namespace focr {
 // src/ncc.rs:264-268).
 struct SizeClass {
     uint32_t n_w, n_h;
-    uint32_t ndw;          // dwords per padded template row in the direct kernel (1..4)
+    uint32_t ndw;          // dwords per padded template row in the direct kernels (1..4; 5..8 for wide classes)
     uint32_t maxh;         // padded row count in the direct kernel (16 or 32; = n_h for tall classes)
-    bool tall;             // n_h > 32: scanned by scan_tall_kernel in both modes (no MFMA layout)
+    bool tall;             // n_h > 32 or n_w > 16: scanned by scan_tall_kernel in both modes (no MFMA layout)
     uint32_t n_templates;  // templates in this class
     uint32_t first;        // index of the class's first entry in the class-ordered arrays
     // MFMA prefilter layout

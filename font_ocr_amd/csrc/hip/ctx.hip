@@ -267,8 +267,8 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
     for (size_t t = 0; t < n_templates; t++) {
         const focr_template_t &d = templates[t];
         if (d.n_w == 0 || d.n_h == 0) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: empty template");
-        if (d.n_w > 16)  // the reference panics: "not handled", src/ncc.rs:392
-            return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template wider than 16 px is not handled (src/ncc.rs:392)");
+        if (d.n_w > 32)  // the reference panics above 16 ("not handled", src/ncc.rs:392); 17..32 is this build's extension
+            return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template wider than 32 px is not handled");
         if (d.n_h > 255) return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template taller than 255 px is not handled");
         if ((size_t)d.offset + (size_t)d.n_w * d.n_h > needles_len)
             return fail(c, FOCR_ERR_INVALID, "focr_bank_upload: template offset out of range");
@@ -291,7 +291,7 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
             sc.n_w = templates[t].n_w;
             sc.n_h = templates[t].n_h;
             sc.ndw = (sc.n_w + 3) / 4;
-            sc.tall = sc.n_h > 32;
+            sc.tall = sc.n_h > 32 || sc.n_w > 16;
             sc.maxh = sc.tall ? sc.n_h : (sc.n_h <= 16 ? 16 : 32);
             c->classes.push_back(sc);
             members.emplace_back();

@@ -15,7 +15,7 @@ namespace focr {
 
 constexpr int DTX = 64;  // windows per tile row (one wave)
 constexpr int DTY = 4;   // tile rows (waves per block)
-constexpr int DLDW = 21; // dwords per LDS tile row: covers byte columns [0, 84)
+constexpr int DLDW = 26; // dwords per LDS tile row: covers byte columns [0, 104) = 64 windows + 32 px + alignment
 
 template <int NDW, int MAXH>
 __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restrict__ pages, uint32_t pitch,
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
     }
 }
 
-// Tall templates (32 < n_h <= 255): the window no longer fits in registers, so its rows are re-read from the
+// Tall (32 < n_h <= 255) or wide (16 < n_w <= 32, an extension: the reference panics, src/ncc.rs:392) templates:
+// the window no longer fits in registers, so its rows are re-read from the
 // LDS tile and TC templates are accumulated per pass over the rows (their rows arrive as scalar operands).
 // Same arithmetic, same emission rule.  With sims == nullptr only the key is appended (MFMA mode: the hit joins
 // the candidate list and verify_kernel recomputes its similarity with the other candidates).
@@ -194,6 +195,10 @@ int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float 
         case 2: launch_tall_one<2>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
         case 3: launch_tall_one<3>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
         case 4: launch_tall_one<4>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
+        case 5: launch_tall_one<5>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
+        case 6: launch_tall_one<6>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
+        case 7: launch_tall_one<7>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
+        case 8: launch_tall_one<8>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
         default: return fail(c, FOCR_ERR_INVALID, "scan_tall: unsupported size class");
     }
     FOCR_HIP(c, hipGetLastError());

@@ -211,23 +211,28 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
     const uint32_t page = fmt.page(key), t = fmt.t(key), x = fmt.x(key), y = fmt.y(key);
     const uint32_t ci = order_of[t];
     const TemplateConst c = tc[ci];
-    const v4i *nd = needles16 + needle16_row[ci];  // n_h rows of 16 bytes, zero padded past n_w
+    // template rows: 16 bytes each, zero padded past n_w (two 16-byte halves per row for the 17..32-wide extension)
+    const uint32_t halves = c.n_w > 16 ? 2 : 1;
+    const v4i *nd = needles16 + needle16_row[ci];
     const uint8_t *pg = pages + ((size_t)page * rows_alloc + y) * pitch + x;  // rows have >= 64 readable bytes past r_w
-    // byte mask of the window's own n_w columns (the padded template columns are zero, but s_p / s2_p need the mask)
-    v4i keep;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        keep[k] = c.n_w >= (uint32_t)(4 * k + 4) ? -1 : (c.n_w <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (c.n_w - 4 * k))) - 1u));
     uint32_t acc = 0, s_p = 0, s2_p = 0;
-#pragma unroll 8
-    for (uint32_t j = 0; j < c.n_h; j++) {
-        const v4i a = *reinterpret_cast<const v4i_u *>(pg + (size_t)j * pitch) & keep;
-        const v4i b = nd[j];
+    for (uint32_t hf = 0; hf < halves; hf++) {
+        // byte mask of the window's own columns (the padded template columns are zero, but s_p / s2_p need the mask)
+        const uint32_t w_here = min(c.n_w - 16 * hf, 16u);
+        v4i keep;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
-            s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
-            s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
+        for (int k = 0; k < 4; k++)
+            keep[k] = w_here >= (uint32_t)(4 * k + 4) ? -1 : (w_here <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (w_here - 4 * k))) - 1u));
+#pragma unroll 8
+        for (uint32_t j = 0; j < c.n_h; j++) {
+            const v4i a = *reinterpret_cast<const v4i_u *>(pg + (size_t)j * pitch + 16 * hf) & keep;
+            const v4i b = nd[j * halves + hf];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
+                s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
+                s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
+            }
         }
     }
     const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
@@ -370,8 +375,9 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
         const TemplateConst &tc = c->h_tconst[ci];
         n16_row[ci] = (uint32_t)(n16.size() / 16);
         const uint8_t *nd = dense + c->h_needle_off[ci];
+        const uint32_t row_bytes = tc.n_w > 16 ? 32 : 16;
         for (uint32_t j = 0; j < tc.n_h; j++)
-            for (uint32_t x = 0; x < 16; x++) n16.push_back(x < tc.n_w ? nd[j * tc.n_w + x] : 0);
+            for (uint32_t x = 0; x < row_bytes; x++) n16.push_back(x < tc.n_w ? nd[j * tc.n_w + x] : 0);
     }
     FOCR_HIP(c, hipMalloc((void **)&c->d_needles16, n16.size() ? n16.size() : 16));
     FOCR_HIP(c, hipMemcpy(c->d_needles16, n16.data(), n16.size(), hipMemcpyHostToDevice));

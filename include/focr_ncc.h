@@ -87,9 +87,10 @@ enum {
 };
 
 /* One template of the bank: a dense n_w x n_h A8 glyph raster (canvas pixels
- * verbatim, src/ncc.rs:640-641, 894-896).  n_w <= 16 (the reference panics
- * above that, src/ncc.rs:392), 1 <= n_h <= 255 (heights above 32 take a slower
- * exact kernel).  Templates are indexed in
+ * verbatim, src/ncc.rs:640-641, 894-896).  n_w <= 16 as in the reference (it
+ * panics above that, src/ncc.rs:392); 17 <= n_w <= 32 is accepted as an
+ * extension.  1 <= n_h <= 255.  Heights above 32 and widths above 16 take a
+ * slower exact kernel.  Templates are indexed in
  * get_hits order: sub-pixel offset major, alphabet order minor
  * (src/ncc.rs:587, 630). */
 typedef struct focr_template {

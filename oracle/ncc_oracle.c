@@ -134,7 +134,10 @@ void oracle_copy_needle(const uint8_t *needle, size_t n_w, size_t n_h, size_t N,
 }
 
 /* ncc_8_u8 / ncc_16_u8, src/ncc.cpp:48-251 / 253-396, restated as one scalar
- * routine over an N-wide (N = 8 or 16) zero-padded needle.
+ * routine over an N-wide (N = 8 or 16) zero-padded needle.  N = 32 is this
+ * build's extension for templates 17..32 px wide (the reference panics there,
+ * src/ncc.rs:392): the same arithmetic, no
+ * reference behaviour to pin it against.
  *
  *   acc  = sum_{j<n_h} sum_{i<N} T[j][i] * R[y+j][x+i]        (ncc.cpp:316-321)
  *   num  = fma(-((double)s_n * (double)s_p), 1/n, (double)acc) (ncc.cpp:212, 358)
@@ -163,12 +166,19 @@ static inline uint32_t dot_rows_16(const uint8_t *r, size_t r_w, const uint8_t *
     return acc;
 }
 
+static inline uint32_t dot_rows_32(const uint8_t *r, size_t r_w, const uint8_t *t, size_t n_h) {
+    uint32_t acc = 0;
+    for (size_t j = 0; j < n_h; j++)
+        for (size_t i = 0; i < 32; i++) acc += (uint32_t)t[j * 32 + i] * (uint32_t)r[j * r_w + i];
+    return acc;
+}
+
 size_t oracle_ncc_u8(const uint8_t *reference, size_t r_w, size_t r_h, const uint8_t *needle_N,
                      size_t N, size_t n_w, size_t n_h, const uint32_t *patch_sum,
                      const double *patch_rnorm, const uint16_t *start_end, float threshold,
                      OracleMatch *out, size_t n_out) {
     size_t n = n_w * n_h;
-    if (r_h < n_h || n_out == 0 || (N != 8 && N != 16)) return 0;
+    if (r_h < n_h || n_out == 0 || (N != 8 && N != 16 && N != 32)) return 0;
     size_t y_searches = r_h - n_h + 1;
 
     uint32_t s_n = 0, s2_n = 0; /* ncc.cpp:73-81, 278-286 */
@@ -189,7 +199,8 @@ size_t oracle_ncc_u8(const uint8_t *reference, size_t r_w, size_t r_h, const uin
         size_t start = start_end[y * 2 + 0], end = start_end[y * 2 + 1];
         for (size_t x = start; x < end; x++) {
             const uint8_t *r0 = reference + y * r_w + x;
-            uint32_t acc = N == 8 ? dot_rows_8(r0, r_w, needle_N, n_h) : dot_rows_16(r0, r_w, needle_N, n_h);
+            uint32_t acc = N == 8 ? dot_rows_8(r0, r_w, needle_N, n_h)
+                           : N == 16 ? dot_rows_16(r0, r_w, needle_N, n_h) : dot_rows_32(r0, r_w, needle_N, n_h);
             double acc_d = (double)(int32_t)acc;
             double s_p_d = (double)(int32_t)patch_sum[y * r_w + x];
             double num = fma(-(s_n_d * s_p_d), n_recip, acc_d);
@@ -320,23 +331,23 @@ size_t oracle_scan_page(const uint8_t *page, size_t r_w, size_t r_h, const uint8
     uint16_t *start_end = (uint16_t *)calloc(r_h * 2, 2);
     size_t acc_len = r_w * 8 + 8; /* src/ncc.rs:242 */
     uint32_t *acc = (uint32_t *)calloc(acc_len + 8, 4);
-    uint8_t needle_N[16 * 64];
+    uint8_t needle_N[32 * 256];
     oracle_sum_table(page, r_w, r_h, sum_table);
     oracle_sumsqr_table(page, r_w, r_h, sumsqr_table);
     size_t last_w = 0, last_h = 0, total = 0;
     for (size_t t = 0; t < n_templates; t++) {
         size_t n_w = tmpl[t].n_w, n_h = tmpl[t].n_h;
         counts[t] = 0;
-        if (n_w == 0 || n_h == 0 || n_w > 16 || n_h > 64 || n_w > r_w || n_h > r_h) continue;
+        if (n_w == 0 || n_h == 0 || n_w > 32 || n_h > 255 || n_w > r_w || n_h > r_h) continue;
         if (n_w != last_w || n_h != last_h) {
             oracle_prepare_for_size(sum_table, sumsqr_table, r_w, r_h, n_w, n_h, patch_sum,
                                     patch_rnorm, start_end);
             last_w = n_w;
             last_h = n_h;
         }
-        size_t N = n_w <= 8 ? 8 : 16;
+        size_t N = n_w <= 8 ? 8 : n_w <= 16 ? 16 : 32;
         oracle_copy_needle(needles + tmpl[t].offset, n_w, n_h, N, needle_N);
-        ncc_kernel_fn k = N == 8 ? k8 : k16;
+        ncc_kernel_fn k = N == 8 ? k8 : N == 16 ? k16 : NULL; /* no reference kernel for the N = 32 extension */
         size_t c;
         if (k)
             c = k(page, r_w, r_h, needle_N, n_w, n_h, acc, acc_len, patch_sum, patch_rnorm, start_end,

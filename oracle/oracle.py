@@ -114,9 +114,9 @@ def prepare_for_size(page_inv, n_w, n_h, tabs=None):
 
 
 def pad_needle(needle):
-    """copy_needle_n_u8 (src/ncc.rs:925-935): (n_h, n_w) -> (n_h, N) with N = 8 | 16."""
+    """copy_needle_n_u8 (src/ncc.rs:925-935): (n_h, n_w) -> (n_h, N) with N = 8 | 16 (| 32: this build's extension)."""
     n_h, n_w = needle.shape
-    N = 8 if n_w <= 8 else 16
+    N = 8 if n_w <= 8 else 16 if n_w <= 16 else 32
     out = np.zeros((n_h, N), np.uint8)
     out[:, :n_w] = needle
     return out

@@ -125,3 +125,28 @@ def test_cli_spaces_extension(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.splitlines() == [w.replace(" ", "") for w in want]
+
+
+@pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")
+def test_cli_wide_templates_extension(tmp_path):
+    """-t 30 gives 19 px wide templates: the reference panics ("not handled", src/ncc.rs:392) and so does the default
+    CLI; --allow-wide (extension) scans them with the exact kernel and reads the stamped text back."""
+    alphabet = ASCII95[33:59]  # A..Z
+    bank = Bank.rasterize(FONT, 30, 1, 0, alphabet=alphabet)
+    assert int(bank.templates["n_w"].max()) > 16
+    page, truth = synth_page(bank, SYNTH_SEED_BASE + 950, 700, 220, with_truth=True)
+    path = str(tmp_path / "big.pgm")
+    save_pgm(path, page)
+    cmd = [NCC, "-f", FONT, "-t", "30", "--x-bits", "1", "-a", alphabet, "-i", path]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 101 and "not handled" in r.stderr
+    r = subprocess.run(cmd + ["--allow-wide"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    counts, matches = O.scan_page(O.invert(page), bank, 0.8)
+    want = O.process_hits(O.raw_hits(counts, matches, bank), 0.95, 5)
+    assert r.stdout == "".join("".join(chr(int(c)) for c in l["letter"]) + "\n" for l in want)
+    lines = {}
+    for t in truth:
+        lines.setdefault(int(t["y"]), []).append((int(t["x"]), chr(int(t["letter"]))))
+    stamped = ["".join(ch for _, ch in sorted(v)) for _, v in sorted(lines.items())]
+    assert r.stdout.splitlines() == stamped and len(stamped) >= 3

@@ -238,7 +238,8 @@ def _random_bank(rng, shapes, per_shape):
     [(9, 17), (11, 32), (4, 30), (16, 32)],    # tall templates: 6 / 8 K-steps
     [(9, 33), (16, 48), (5, 40), (13, 64), (9, 15)],  # n_h > 32: scan_tall_kernel (plus one MFMA class)
     [(7, 58), (16, 70)],                       # only tall classes; 70 > page height: never searchable
-], ids=["w16", "w8", "w12", "tall", "taller", "tallest"])
+    [(17, 5), (24, 20), (32, 33), (20, 40), (9, 15)],  # 17..32 px wide (extension; the oracle generalises to N = 32)
+], ids=["w16", "w8", "w12", "tall", "taller", "tallest", "wide"])
 def test_random_banks_all_layouts(scanner, mode, shapes):
     rng = np.random.default_rng(hash(str(shapes)) % 2**32)
     bank = _random_bank(rng, shapes, 7)
@@ -272,9 +273,13 @@ def test_c3_bank_16_shifts(scanner, bank_x2y2, mode):
 def test_wide_template_is_rejected(scanner):
     from font_ocr_amd.searcher import FocrError
 
-    bank = _random_bank(np.random.default_rng(0), [(17, 5)], 1)
-    with pytest.raises(FocrError, match="wider than 16"):  # the reference panics: "not handled", src/ncc.rs:392
+    bank = _random_bank(np.random.default_rng(0), [(33, 5)], 1)
+    with pytest.raises(FocrError, match="wider than 32"):  # the reference panics above 16 ("not handled", src/ncc.rs:392)
         scanner.set_bank(bank)
+    from font_ocr_amd.searcher import Searcher
+
+    with pytest.raises(FocrError, match="not handled"):  # the drop-in symbols keep the reference's limit
+        Searcher(np.zeros((40, 40), np.uint8)).search_c_u8(np.ones((5, 17), np.uint8), (None, None, None), 0.8)
 
 
 @pytest.mark.parametrize("mode", MODES)
