@@ -46,8 +46,8 @@ def traffic_of(kernel_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pages-per-gpu", type=int, default=128)
     ap.add_argument("--config", choices=["c2", "c3"], default="c2",
                     help="c2 = BASELINE configs[1] (608x720, 380 templates; the headline workload); c3 = configs[2] geometry "

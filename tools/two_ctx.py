@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--pages", type=int, default=128)
     ap.add_argument("--cus", type=int, default=0, help="CUs for the scan kernel (0 = all)")
+    ap.add_argument("--no-post", action="store_true", help="ablation: skip process_hits")
     a = ap.parse_args()
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
     pages = synth_pages(bank, a.pages, 608, 720)
@@ -43,7 +44,8 @@ def main():
     def work(sc):
         for _ in range(a.steps):
             sc.scan(0.8, 1024, SCAN_MFMA)
-            sc.process_hits(0.95, 5)
+            if not a.no_post:
+                sc.process_hits(0.95, 5)
         sc.sync()
 
     out = {}
