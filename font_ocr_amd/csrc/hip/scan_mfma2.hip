@@ -45,10 +45,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 
     const uint32_t total_mt = *live_count;  // live 16-window M-tiles of this pass (blank paper is skipped)
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    const uint32_t n_waves = gridDim.x * NW;
+    // XCD-aware work split: workgroups b and b + 8 share an XCD (its own L2), so the 8 residue classes of
+    // blockIdx.x each take one contiguous eighth of the work list (= their own pages and image rows, which the
+    // 15 window rows touching them then find in that L2) and stride through it by the waves of the class.
+    const uint32_t n_xc = min(8u, gridDim.x);               // small launches have fewer classes than XCDs
+    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
+    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;  // workgroups in this residue class
+    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
+    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
+    const uint32_t stride = xc_blocks * NW;
 
     v4i afrag[MT][KSTEPS];
-    for (uint32_t item = blockIdx.x * NW + w; item < n_items; item += n_waves) {
+    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
         // coordinates of the item's M-tiles (wave-uniform, scalar loads)
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
         }
         // A fragments: lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r.
         // Byte-unaligned 16-byte (8-byte) global loads land directly in the MFMA operand registers.
-        if (!(dbg & 2) || item == blockIdx.x * NW + w)
+        if (!(dbg & 2) || item == xc * per_xc + slot * NW + w)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + ((dbg & 4) ? 0 : r);
