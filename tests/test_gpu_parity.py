@@ -490,3 +490,36 @@ def test_three_contexts_on_three_threads(bank_x2):
     for j in range(n_ctx):
         for r in range(rounds):
             _assert_same(got[j][r], want[j][r], f"context {j} round {r}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("shape", [(18, 65535), (65535, 18), (40, 5001)], ids=["widest", "tallest", "odd"])
+def test_extreme_page_geometry(scanner, bank_x2, mode, shape):
+    """Page sides up to the u16 limit of Match.x / Match.y (src/ncc.cpp:7-10): one text line's worth of rows by
+    65535 columns and the transpose; key packing, tile grids and the work list must all hold."""
+    r_h, r_w = shape
+    rng = np.random.default_rng(r_h * 7 + r_w)
+    page = np.full((r_h, r_w), 255, np.uint8)
+    # sprinkle glyphs (anywhere they fit) and some noise so that there are hits near every border
+    for k in range(400):
+        t = int(rng.integers(0, len(bank_x2)))
+        nd = bank_x2.needle(t)
+        if nd.shape[0] > r_h or nd.shape[1] > r_w:
+            continue
+        y = int(rng.integers(0, r_h - nd.shape[0] + 1))
+        x = int(rng.integers(0, r_w - nd.shape[1] + 1))
+        if k % 4 == 0:
+            x = [0, 1, r_w - nd.shape[1], r_w - nd.shape[1] - 1][(k // 4) % 4]
+        if k % 4 == 1:
+            y = [0, 1, r_h - nd.shape[0], r_h - nd.shape[0] - 1][(k // 4) % 4] if r_h > nd.shape[0] + 1 else 0
+        page[y:y + nd.shape[0], x:x + nd.shape[1]] = 255 - nd
+    pages = page[None]
+    scanner.set_bank(bank_x2)
+    scanner.set_pages(pages)
+    scanner.scan(0.8, 1024, mode)
+    offsets, m = scanner.matches()
+    want = _oracle_lists(pages, bank_x2, 0.8, 1024)
+    _assert_same(_csr_to_lists(offsets, m, 1, len(bank_x2)), want, f"{shape}")
+    assert sum(len(x) for x in want[0]) > 100
+    with pytest.raises(Exception, match="65535"):
+        scanner.alloc_pages(1, 65536, 20)
