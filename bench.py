@@ -74,6 +74,10 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # several host threads drive the GPU (one per context in flight, one for the gather); their Python sections are
+    # tiny, but a thread that needs the GIL back after a blocking call must not wait the default 5 ms for it
+    sys.setswitchinterval(5e-5)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,39 +138,65 @@ def main():
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
-    pending = []  # earlier steps' gathers, still in flight on RCCL's stream while later steps scan
+    import queue
+    import threading
+
     pool = ThreadPoolExecutor(max_workers=n_ctx)  # one host thread per context (ctypes calls release the GIL)
     jobs = deque()  # (context index, future) of the steps in flight, oldest first
 
-    def gather_lines(c_):
-        """RCCL gather of the post-processed characters (variable length, device resident) to rank 0.  Launched
-        asynchronously: it overlaps later steps' scans and is waited for a step later (and before the clock stops).
-        Only the main thread issues collectives, in step order, so every rank issues them in the same order."""
-        ptr, cnt = c_.device_chars()
-        nbytes = cnt * HIT_DTYPE.itemsize
-        if nbytes:
-            mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev).clone()  # private copy: the context is reused next
-        else:
-            mine = torch.zeros(0, dtype=torch.uint8, device=dev)
-        torch.cuda.current_stream().synchronize()
-        pending.append(gather_chars(mine, rank, world, dev, async_op=True))
-        n_prev = 0
-        while len(pending) > 1:
-            allc = pending.pop(0)()
-            n_prev = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
-        return n_prev
+    cloned = [threading.Event() for _ in range(n_ctx)]  # context j's characters of its last step have been copied out
+    for ev_ in cloned:
+        ev_.set()
 
-    def drain_gathers():
-        n_last = 0
-        while pending:
-            allc = pending.pop(0)()
-            n_last = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
-        return n_last
-
-    def run_step(c_):  # one pass of the hot path over one resident batch (worker thread)
+    def run_step(c_, j=None):  # one pass of the hot path over one resident batch (worker thread)
         c_.scan(args.threshold, 1024, mode)
+        if j is not None:
+            cloned[j].wait()  # the gather thread still reads the previous step's characters of this context
         c_.process_hits(0.95, 5)
-        return c_.launches(), c_.timings(), c_.total_chars()
+        chars_at = c_.device_chars() if j is not None else None  # (device pointer, count), valid until the next process_hits
+        return c_.launches(), c_.timings(), c_.total_chars(), chars_at
+
+    # The only collective of the path: the RCCL gather of the post-processed characters (variable length, device
+    # resident) to rank 0.  One dedicated thread issues the collectives, strictly in step order, so every rank
+    # issues them in the same order; each gather is asynchronous on RCCL's stream and is waited for one step later.
+    gather_q = queue.Queue()
+    gathered = {"chars": 0, "err": None}
+
+    def gather_worker():
+        torch.cuda.set_device(local_rank)  # the current device is per thread
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # keep off the legacy null stream (see run_step)
+        pending = []
+        while True:
+            item = gather_q.get()
+            try:
+                mine = None
+                if item is not None:  # private copy of the characters, then the context may overwrite them
+                    j, (ptr, cnt) = item
+                    nbytes = cnt * HIT_DTYPE.itemsize
+                    if nbytes:
+                        mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev).clone()
+                    else:
+                        mine = torch.zeros(0, dtype=torch.uint8, device=dev)
+                    torch.cuda.current_stream(dev).synchronize()
+                    cloned[j].set()
+                if mine is None:  # drain request
+                    while pending:
+                        allc = pending.pop(0)()
+                        gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+                else:
+                    pending.append(gather_chars(mine, rank, world, dev, async_op=True))
+                    while len(pending) > 1:
+                        allc = pending.pop(0)()
+                        gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+            except Exception as e:  # noqa: BLE001 - reported by fence()
+                gathered["err"] = e
+                for ev_ in cloned:  # never leave a worker waiting
+                    ev_.set()
+            finally:
+                gather_q.task_done()
+
+    if use_dist:
+        threading.Thread(target=gather_worker, daemon=True).start()
 
     kern = {}
     phase = {}
@@ -177,7 +207,7 @@ def main():
         """Consume the oldest step in flight: its results stay on the device; with several ranks they are gathered."""
         nonlocal n_chars
         j, fut = jobs.popleft()
-        launches, timings, chars = fut.result()
+        launches, timings, chars, chars_at = fut.result()
         if timed:
             for li in launches:
                 k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
@@ -185,19 +215,29 @@ def main():
                 k["n"] += 1
             for k_, v in timings.items():
                 phase[k_] = phase.get(k_, 0.0) + v
-        n_chars = (gather_lines(scs[j]) if use_dist else chars) or n_chars
+        if use_dist:
+            cloned[j].clear()
+            gather_q.put((j, chars_at))
+        else:
+            n_chars = chars or n_chars
 
     def step(k):
         if len(jobs) == n_ctx:  # context k % n_ctx is still busy with step k - n_ctx
             retire()
-        jobs.append((k % n_ctx, pool.submit(run_step, scs[k % n_ctx])))
+        jobs.append((k % n_ctx, pool.submit(run_step, scs[k % n_ctx], k % n_ctx if use_dist else None)))
 
     def fence():
+        nonlocal n_chars
         while jobs:
             retire()
         for c_ in scs:
             c_.sync()
-        drain_gathers()
+        if use_dist:
+            gather_q.put(None)
+            gather_q.join()
+            if gathered["err"] is not None:
+                raise gathered["err"]
+            n_chars = gathered["chars"] or n_chars
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -210,10 +250,6 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
-    while jobs:
-        retire()
-    if use_dist:
-        n_chars = drain_gathers() or n_chars
     fence()
     dt = time.perf_counter() - t0
     timed = False

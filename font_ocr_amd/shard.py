@@ -31,7 +31,13 @@ def gather_chars(mine, rank, world, device=None, async_op=False):
     n = torch.tensor([mine.numel()], device=dev, dtype=torch.int64)
     all_n = torch.empty(world, device=dev, dtype=torch.int64)
     dist.all_gather_into_tensor(all_n, n)
-    sizes = all_n.tolist()  # one device->host read for all ranks' sizes
+    if all_n.is_cuda:  # one device->host read for all ranks' sizes, waited for with the GIL released
+        host_n = torch.empty(world, dtype=torch.int64, pin_memory=True)
+        host_n.copy_(all_n, non_blocking=True)
+        torch.cuda.current_stream(all_n.device).synchronize()
+        sizes = host_n.tolist()
+    else:
+        sizes = all_n.tolist()
     mx = max(max(sizes), 1)
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[: mine.numel()] = mine
