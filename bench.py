@@ -44,6 +44,10 @@ def traffic_of(kernel_name):
 
 
 def main():
+    # ROCm maps a process's streams onto 4 hardware queues by default; three contexts + the gather's streams + RCCL's
+    # are more than that, and a small copy sharing a queue with a context waits behind its 2.5 ms scan kernel
+    # (measured: the gather path at 17.6 instead of 21.0 Gpx/s).  Must be set before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -111,6 +115,11 @@ def main():
     n_ctx = max(1, args.in_flight)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_ctx == 1 else n_cus - n_cus // 8)
+    # The executor: n_ctx contexts with a native worker thread each (focr_pipe_*, include/focr_ncc.h)
+    from font_ocr_amd.searcher import Pipeline
+
+    pipe = Pipeline(local_rank, n_ctx)
+    pipe.set_bank(bank)
     scs, pages = [], None
     for j in range(n_ctx):  # every rank (and every context of it) scans its own shard of the page set
         if args.noise:
@@ -119,8 +128,7 @@ def main():
             pg = synth_pages(bank, P, R_W, R_H, first=(rank * n_ctx + j) * P)
         if j == 0:
             pages = pg
-        c_ = Scanner(local_rank)
-        c_.set_bank(bank)
+        c_ = pipe.scanners[j]
         c_.set_scan_cus(scan_cus)
         # inputs resident in HBM before the timed region: pages go up as a torch tensor, then device->device ingest
         d_pages = torch.from_numpy(pg).to(dev)
@@ -136,66 +144,59 @@ def main():
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
     from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
-
     import queue
     import threading
 
-    pool = ThreadPoolExecutor(max_workers=n_ctx)  # one host thread per context (ctypes calls release the GIL)
-    jobs = deque()  # (context index, future) of the steps in flight, oldest first
+    jobs = deque()  # tickets of the steps in flight, oldest first
 
-    cloned = [threading.Event() for _ in range(n_ctx)]  # context j's characters of its last step have been copied out
-    for ev_ in cloned:
-        ev_.set()
-
-    def run_step(c_, j=None):  # one pass of the hot path over one resident batch (worker thread)
+    def run_step(c_):  # one pass of the hot path over one resident batch, synchronously on one context
         c_.scan(args.threshold, 1024, mode)
-        if j is not None:
-            cloned[j].wait()  # the gather thread still reads the previous step's characters of this context
         c_.process_hits(0.95, 5)
-        chars_at = c_.device_chars() if j is not None else None  # (device pointer, count), valid until the next process_hits
-        return c_.launches(), c_.timings(), c_.total_chars(), chars_at
 
     # The only collective of the path: the RCCL gather of the post-processed characters (variable length, device
-    # resident) to rank 0.  One dedicated thread issues the collectives, strictly in step order, so every rank
-    # issues them in the same order; each gather is asynchronous on RCCL's stream and is waited for one step later.
+    # resident) to rank 0.  retire() copies a finished step's characters out of its context (which is then released
+    # for its next batch); one dedicated thread issues the collectives, strictly in step order, so every rank issues
+    # them in the same order; each gather is asynchronous on RCCL's stream and is waited for one step later.
     gather_q = queue.Queue()
     gathered = {"chars": 0, "err": None}
 
     def gather_worker():
         torch.cuda.set_device(local_rank)  # the current device is per thread
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # keep off the legacy null stream (see run_step)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # keep off the legacy null stream
         pending = []
         while True:
             item = gather_q.get()
             try:
-                mine = None
-                if item is not None:  # private copy of the characters, then the context may overwrite them
-                    j, (ptr, cnt) = item
-                    nbytes = cnt * HIT_DTYPE.itemsize
-                    if nbytes:
-                        mine = torch.as_tensor(_DevBytes(ptr, nbytes), device=dev).clone()
-                    else:
-                        mine = torch.zeros(0, dtype=torch.uint8, device=dev)
-                    torch.cuda.current_stream(dev).synchronize()
-                    cloned[j].set()
-                if mine is None:  # drain request
+                def finish_oldest():
+                    fin, slot = pending.pop(0)
+                    allc = fin()
+                    torch.cuda.current_stream(dev).synchronize()  # the gather has read the slot
+                    slot_free[slot].set()
+                    gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+
+                if item is None:  # drain request
                     while pending:
-                        allc = pending.pop(0)()
-                        gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+                        finish_oldest()
                 else:
-                    pending.append(gather_chars(mine, rank, world, dev, async_op=True))
+                    slot, nbytes = item
+                    pending.append((gather_chars(out_bufs[slot][:nbytes], rank, world, dev, async_op=True), slot))
                     while len(pending) > 1:
-                        allc = pending.pop(0)()
-                        gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+                        finish_oldest()
             except Exception as e:  # noqa: BLE001 - reported by fence()
                 gathered["err"] = e
-                for ev_ in cloned:  # never leave a worker waiting
+                for ev_ in slot_free:  # never leave the submitter waiting
                     ev_.set()
             finally:
                 gather_q.task_done()
 
     if use_dist:
+        # device slots the lanes copy their characters into (two per lane, so a slot is rewritten 2 * n_ctx steps later)
+        slot_bytes = max(1 << 20, 2 * P * (R_W // 6) * (R_H // 12) * HIT_DTYPE.itemsize)  # twice a page full of text
+        out_bufs = [torch.empty(slot_bytes, dtype=torch.uint8, device=dev) for _ in range(2 * n_ctx)]
+        slot_free = [threading.Event() for _ in out_bufs]
+        for ev_ in slot_free:
+            ev_.set()
+        slot_of, next_slot = {}, [0]
         threading.Thread(target=gather_worker, daemon=True).start()
 
     kern = {}
@@ -206,38 +207,50 @@ def main():
     def retire():
         """Consume the oldest step in flight: its results stay on the device; with several ranks they are gathered."""
         nonlocal n_chars
-        j, fut = jobs.popleft()
-        launches, timings, chars, chars_at = fut.result()
+        t = jobs.popleft()
+        c_ = pipe.wait(t)
         if timed:
-            for li in launches:
+            for li in c_.launches():
                 k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
                 k["ms"] += li["ms"]
                 k["n"] += 1
-            for k_, v in timings.items():
+            for k_, v in c_.timings().items():
                 phase[k_] = phase.get(k_, 0.0) + v
-        if use_dist:
-            cloned[j].clear()
-            gather_q.put((j, chars_at))
+        if use_dist:  # the lane already copied the characters into its output slot: free it for its next batch
+            slot = slot_of.pop(t)
+            nbytes = c_.total_chars() * HIT_DTYPE.itemsize
+            pipe.release(t)
+            gather_q.put((slot, nbytes))
         else:
-            n_chars = chars or n_chars
+            n_chars = c_.total_chars() or n_chars
+            pipe.release(t)
 
     def step(k):
-        if len(jobs) == n_ctx:  # context k % n_ctx is still busy with step k - n_ctx
+        if len(jobs) == n_ctx:  # the lane this step maps to still holds step k - n_ctx
             retire()
-        jobs.append((k % n_ctx, pool.submit(run_step, scs[k % n_ctx], k % n_ctx if use_dist else None)))
+        if use_dist:
+            slot = next_slot[0] % len(out_bufs)
+            next_slot[0] += 1
+            slot_free[slot].wait()  # its previous gather (2 * n_ctx steps ago) has read it
+            slot_free[slot].clear()
+            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, chars_out=(out_bufs[slot].data_ptr(), out_bufs[slot].numel()))
+            slot_of[t] = slot
+        else:
+            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5)
+        jobs.append(t)
 
     def fence():
         nonlocal n_chars
         while jobs:
             retire()
-        for c_ in scs:
-            c_.sync()
         if use_dist:
             gather_q.put(None)
             gather_q.join()
             if gathered["err"] is not None:
                 raise gathered["err"]
             n_chars = gathered["chars"] or n_chars
+        for c_ in scs:
+            c_.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -281,18 +294,18 @@ def main():
             pin.array[:] = pages
             pins.append(pin)
 
-        def run_step_upload(j):
-            scs[j].upload_pages(pins[j].array, 0, invert=True)
-            return run_step(scs[j])
-
         def pipe_steps(n):
-            futs = deque()
+            tickets = deque()
             for k in range(n):
-                if len(futs) == n_ctx:
-                    futs.popleft().result()
-                futs.append(pool.submit(run_step_upload, k % n_ctx))
-            while futs:
-                futs.popleft().result()
+                if len(tickets) == n_ctx:
+                    t = tickets.popleft()
+                    pipe.wait(t)
+                    pipe.release(t)
+                tickets.append(pipe.submit(pins[k % n_ctx].array, args.threshold, 1024, mode, True, 0.95, 5))
+            while tickets:
+                t = tickets.popleft()
+                pipe.wait(t)
+                pipe.release(t)
 
         pipe_steps(n_ctx)
         fence()
@@ -426,9 +439,7 @@ def main():
 
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    pool.shutdown()
-    for c_ in scs:
-        c_.close()
+    pipe.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -103,6 +103,16 @@ HIP_SYMBOLS = {
     "focr_last_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "focr_sync": (C.c_int, [C.c_void_p]),
     "focr_ctx_set_scan_cus": (C.c_int, [C.c_void_p, C.c_uint]),
+    "focr_pipe_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "focr_pipe_destroy": (None, [C.c_void_p]),
+    "focr_pipe_contexts": (C.c_uint, [C.c_void_p]),
+    "focr_pipe_context": (C.c_void_p, [C.c_void_p, C.c_uint]),
+    "focr_pipe_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "focr_pipe_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_float,
+                                   C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_uint64)]),
+    "focr_pipe_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "focr_pipe_release": (C.c_int, [C.c_void_p, C.c_uint64]),
     "focr_last_launches": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_debug_rnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -251,6 +251,7 @@ struct PhaseClock {  // -v: wall time of each host phase, on stderr
 };
 
 int main(int argc, char **argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);  // more streams than the default 4 hardware queues must not share one
     Args args = parse_args(argc, argv);
     PhaseClock clk{args.verbose};
     int box = args.box_size == "font" ? FOCR_BOX_FONT : args.box_size == "alphabet" ? FOCR_BOX_ALPHABET : args.box_size == "char" ? FOCR_BOX_CHAR : -1;

@@ -1,0 +1,214 @@
+// pipe.hip — batches in flight: n contexts on one device, one worker thread each, batches handed out round-robin.
+//
+// The reference parallelises over pages with a rayon pool (src/ncc.rs:839-847).  On the GPU the unit is a batch of
+// pages, and what has to overlap is one batch's latency-bound small kernels (statistics, sorts, verify, ordering,
+// process_hits) with another batch's MFMA scan: that needs the batches on different streams, driven by different
+// host threads (focr_scan has host round trips for the candidate / hit counts).  This file is that executor, so a
+// host in any language gets the overlap from submit / wait / release without writing thread code.
+// DESIGN.md section 5 ("Batches in flight") has the measurements.
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "common.h"
+
+namespace focr {
+
+struct PipeJob {
+    const void *pages = nullptr;  // nullptr: rescan the pages already resident in the lane's context
+    int on_device = 0, invert = 0, mode = 0;
+    size_t n_pages = 0, r_w = 0, r_h = 0;
+    float threshold = 0.f, anchor_threshold = 0.f;
+    uint32_t cap = 0;
+    int32_t overlap = 0;
+    int post = 1;
+    void *chars_out = nullptr;  // device buffer that receives a copy of the batch's characters (focr_hit_t[])
+    size_t chars_cap = 0;       // its size in bytes
+};
+
+struct PipeLane {
+    enum State { IDLE, QUEUED, RUNNING, DONE };
+    focr_ctx *ctx = nullptr;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    State state = IDLE;
+    uint64_t ticket = 0;
+    PipeJob job;
+    int rc = FOCR_OK;
+    bool stop = false;
+};
+
+}  // namespace focr
+
+struct focr_pipe {
+    std::vector<focr::PipeLane *> lanes;
+    std::mutex mu;  // guards next_ticket
+    uint64_t next_ticket = 1;
+};
+
+namespace focr {
+
+static void lane_main(PipeLane *L) {
+    for (;;) {
+        PipeJob job;
+        {
+            std::unique_lock<std::mutex> lk(L->mu);
+            L->cv.wait(lk, [&] { return L->stop || L->state == PipeLane::QUEUED; });
+            if (L->stop) return;
+            L->state = PipeLane::RUNNING;
+            job = L->job;
+        }
+        focr_ctx *c = L->ctx;
+        int rc = FOCR_OK;
+        if (job.pages) {
+            rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
+            if (rc == FOCR_OK)
+                rc = job.on_device ? focr_pages_upload_device(c, 0, job.n_pages, job.pages, job.invert)
+                                   : focr_pages_upload(c, 0, job.n_pages, (const uint8_t *)job.pages, job.invert);
+        }
+        if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
+        if (rc == FOCR_OK && job.post) rc = focr_process_hits(c, job.anchor_threshold, job.overlap);
+        if (rc == FOCR_OK && job.post && job.chars_out) {  // copy-out on the context's own stream: ordered, no other queue involved
+            const size_t bytes = focr_total_chars(c) * sizeof(focr_hit_t);
+            if (bytes > job.chars_cap) {
+                rc = fail(c, FOCR_ERR_OVERFLOW, "focr_pipe_submit: chars_out is too small for this batch");
+            } else if (bytes) {
+                hipError_t e = hipMemcpyAsync(job.chars_out, focr_lines_device_chars(c), bytes, hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: copy-out failed: ") + hipGetErrorString(e));
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            L->rc = rc;
+            L->state = PipeLane::DONE;
+        }
+        L->cv.notify_all();
+    }
+}
+
+}  // namespace focr
+
+using namespace focr;
+
+extern "C" {
+
+int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
+    if (!out || n_contexts < 1 || n_contexts > 8) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_create: 1..8 contexts");
+    *out = nullptr;
+    focr_pipe *p = new focr_pipe();
+    hipDeviceProp_t prop;
+    for (unsigned i = 0; i < n_contexts; i++) {
+        PipeLane *L = new PipeLane();
+        int rc = focr_ctx_create(device, &L->ctx);
+        if (rc != FOCR_OK) {
+            delete L;
+            focr_pipe_destroy(p);
+            return rc;
+        }
+        // several batches in flight: leave one CU of every shader engine (an eighth of the chip) to the small kernels
+        if (n_contexts > 1 && hipGetDeviceProperties(&prop, device) == hipSuccess)
+            focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 8));
+        L->worker = std::thread(lane_main, L);
+        p->lanes.push_back(L);
+    }
+    *out = p;
+    return FOCR_OK;
+}
+
+void focr_pipe_destroy(focr_pipe_t *p) {
+    if (!p) return;
+    for (PipeLane *L : p->lanes) {
+        {
+            std::unique_lock<std::mutex> lk(L->mu);
+            L->cv.wait(lk, [&] { return L->state != PipeLane::QUEUED && L->state != PipeLane::RUNNING; });
+            L->stop = true;
+        }
+        L->cv.notify_all();
+        if (L->worker.joinable()) L->worker.join();
+        focr_ctx_destroy(L->ctx);
+        delete L;
+    }
+    delete p;
+}
+
+unsigned focr_pipe_contexts(const focr_pipe_t *p) { return p ? (unsigned)p->lanes.size() : 0; }
+
+focr_ctx_t *focr_pipe_context(focr_pipe_t *p, unsigned index) {
+    return (p && index < p->lanes.size()) ? p->lanes[index]->ctx : nullptr;
+}
+
+int focr_pipe_bank_upload(focr_pipe_t *p, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
+                          size_t needles_len) {
+    if (!p) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_bank_upload: null pipe");
+    for (PipeLane *L : p->lanes) {
+        {
+            std::unique_lock<std::mutex> lk(L->mu);
+            L->cv.wait(lk, [&] { return L->state == PipeLane::IDLE || L->state == PipeLane::DONE; });
+        }
+        int rc = focr_bank_upload(L->ctx, templates, n_templates, needles, needles_len);
+        if (rc != FOCR_OK) return rc;
+    }
+    return FOCR_OK;
+}
+
+int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, size_t n_pages, size_t r_w, size_t r_h, int invert,
+                     float threshold, uint32_t cap, int mode, int process_hits, float anchor_threshold, int32_t overlap,
+                     void *chars_out, size_t chars_out_bytes, uint64_t *ticket) {
+    if (!p || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_submit: bad arguments");
+    uint64_t t;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        t = p->next_ticket++;
+    }
+    PipeLane *L = p->lanes[(t - 1) % p->lanes.size()];
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        L->cv.wait(lk, [&] { return L->state == PipeLane::IDLE; });  // until the lane's previous batch is released
+        L->job.pages = pages;
+        L->job.on_device = pages_on_device;
+        L->job.n_pages = n_pages;
+        L->job.r_w = r_w;
+        L->job.r_h = r_h;
+        L->job.invert = invert;
+        L->job.threshold = threshold;
+        L->job.cap = cap;
+        L->job.mode = mode;
+        L->job.post = process_hits;
+        L->job.anchor_threshold = anchor_threshold;
+        L->job.overlap = overlap;
+        L->job.chars_out = chars_out;
+        L->job.chars_cap = chars_out_bytes;
+        L->ticket = t;
+        L->state = PipeLane::QUEUED;
+    }
+    L->cv.notify_all();
+    *ticket = t;
+    return FOCR_OK;
+}
+
+int focr_pipe_wait(focr_pipe_t *p, uint64_t ticket, focr_ctx_t **ctx) {
+    if (!p || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_wait: bad arguments");
+    PipeLane *L = p->lanes[(ticket - 1) % p->lanes.size()];
+    std::unique_lock<std::mutex> lk(L->mu);
+    if (L->ticket != ticket || L->state == PipeLane::IDLE) return fail(L->ctx, FOCR_ERR_STATE, "focr_pipe_wait: ticket is not outstanding");
+    L->cv.wait(lk, [&] { return L->state == PipeLane::DONE; });
+    if (ctx) *ctx = L->ctx;
+    return L->rc;
+}
+
+int focr_pipe_release(focr_pipe_t *p, uint64_t ticket) {
+    if (!p || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_release: bad arguments");
+    PipeLane *L = p->lanes[(ticket - 1) % p->lanes.size()];
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        if (L->ticket != ticket || L->state == PipeLane::IDLE) return fail(L->ctx, FOCR_ERR_STATE, "focr_pipe_release: ticket is not outstanding");
+        L->cv.wait(lk, [&] { return L->state == PipeLane::DONE; });
+        L->state = PipeLane::IDLE;
+    }
+    L->cv.notify_all();
+    return FOCR_OK;
+}
+
+}  // extern "C"

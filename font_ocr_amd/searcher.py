@@ -98,19 +98,24 @@ class Searcher:
 class Scanner:
     """Batched device scan: one bank, N resident pages (get_hits' loop, src/ncc.rs:576-701)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._lib = N.hip()
-        h = C.c_void_p()
-        rc = self._lib.focr_ctx_create(int(device), C.byref(h))
-        if rc != 0:
-            raise FocrError(self._lib.focr_last_error_global().decode())
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            h = C.c_void_p()
+            rc = self._lib.focr_ctx_create(int(device), C.byref(h))
+            if rc != 0:
+                raise FocrError(self._lib.focr_last_error_global().decode())
+        else:  # a context that belongs to a Pipeline
+            h = C.c_void_p(_borrowed)
         self._h = h
         self.bank = None
         self.n_pages = self.r_w = self.r_h = 0
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.focr_ctx_destroy(self._h)
+            if self._owned:
+                self._lib.focr_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -239,6 +244,87 @@ class Scanner:
         out = np.zeros(len(s), np.float64)
         self._ck(self._lib.focr_debug_rnorm(self._h, _ptr(s), _ptr(s2), _ptr(n), len(s), _ptr(out)))
         return out
+
+
+class Pipeline:
+    """Batches in flight (focr_pipe_*, include/focr_ncc.h): n contexts on one device with a native worker thread
+    each; submit() hands batches out round-robin, wait() returns the Scanner view of the context holding a batch's
+    results, release() frees that lane for its next batch.  Calls block in native code with the GIL released."""
+
+    def __init__(self, device=0, n_contexts=3):
+        self._lib = N.hip()
+        h = C.c_void_p()
+        rc = self._lib.focr_pipe_create(int(device), int(n_contexts), C.byref(h))
+        if rc != 0:
+            raise FocrError(self._lib.focr_last_error_global().decode())
+        self._h = h
+        self.scanners = [Scanner(device, _borrowed=self._lib.focr_pipe_context(h, i)) for i in range(n_contexts)]
+        self._keep = {}  # ticket -> host array kept alive while its batch is in flight
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for sc in self.scanners:
+                sc.close()
+            self._lib.focr_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_bank(self, bank):
+        rc = self._lib.focr_pipe_bank_upload(self._h, _ptr(bank.templates), len(bank.templates), _ptr(bank.needles), bank.needles.size)
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        for sc in self.scanners:
+            sc.bank = bank
+
+    def submit(self, luma=None, threshold=0.8, cap=MAX_MATCHES, mode=SCAN_MFMA, process_hits=True, anchor_threshold=0.95,
+               overlap=5, invert=True, device_ptr=None, shape=None, chars_out=None):
+        """luma: (n, r_h, r_w) uint8 host pages; or device_ptr + shape=(n, r_h, r_w); or neither = rescan the lane's
+        resident pages.  chars_out=(device pointer, bytes): also copy the batch's characters there.  Returns the ticket."""
+        t = C.c_uint64()
+        if luma is not None:
+            luma = np.ascontiguousarray(luma, np.uint8)
+            if luma.ndim == 2:
+                luma = luma[None]
+            n, r_h, r_w = luma.shape
+            ptr, on_dev = _ptr(luma), 0
+        elif device_ptr is not None:
+            n, r_h, r_w = shape
+            ptr, on_dev = C.c_void_p(int(device_ptr)), 1
+        else:
+            n = r_h = r_w = 0
+            ptr, on_dev = None, 0
+        rc = self._lib.focr_pipe_submit(self._h, ptr, on_dev, n, r_w, r_h, int(bool(invert)), float(threshold), int(cap), int(mode),
+                                        int(bool(process_hits)), float(anchor_threshold), int(overlap),
+                                        C.c_void_p(int(chars_out[0])) if chars_out else None, int(chars_out[1]) if chars_out else 0,
+                                        C.byref(t))
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        if luma is not None:
+            self._keep[t.value] = luma
+        lane = self.scanners[(t.value - 1) % len(self.scanners)]
+        if n:
+            lane.n_pages, lane.r_w, lane.r_h = n, r_w, r_h
+        return t.value
+
+    def wait(self, ticket):
+        """Blocks until the batch is done; returns the Scanner whose getters (matches, lines, counts...) see it."""
+        h = C.c_void_p()
+        rc = self._lib.focr_pipe_wait(self._h, int(ticket), C.byref(h))
+        self._keep.pop(ticket, None)
+        sc = self.scanners[(ticket - 1) % len(self.scanners)]
+        if rc != 0:
+            raise FocrError(f"[{rc}] " + self._lib.focr_last_error(sc._h).decode())
+        return sc
+
+    def release(self, ticket):
+        rc = self._lib.focr_pipe_release(self._h, int(ticket))
+        if rc != 0:
+            raise FocrError(f"[{rc}] focr_pipe_release: ticket is not outstanding")
 
 
 def text_of(lines, advance_px=None):

@@ -201,6 +201,48 @@ int focr_sync(focr_ctx_t *ctx);
  * section 5). */
 int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
 
+/* ---- batches in flight ---------------------------------------------------
+ * The executor form of the page parallelism of src/ncc.rs:839-847 (rayon
+ * par_iter over pages): n contexts on one device, one worker thread each;
+ * batches are handed out round-robin and complete in submission order.  One
+ * batch's small kernels then overlap another's MFMA scan (DESIGN.md section 5:
+ * 15.7 -> 22 Gpx/s at configs[1] with three contexts).  With more than one
+ * context the scan kernel of each is capped to 7/8 of the CUs.
+ *
+ *   focr_pipe_create(dev, 3, &p); focr_pipe_bank_upload(p, ...);
+ *   for each batch b:   if (b >= 3) { wait(t[b-3], &ctx); read results from ctx; release(t[b-3]); }
+ *                       focr_pipe_submit(p, pages_b, ..., &t[b]);
+ *
+ * focr_pipe_submit blocks while the lane it maps to (ticket round-robin) still
+ * holds an unreleased batch.  pages == NULL rescans the pages already resident
+ * in that lane's context (set up through focr_pipe_context).  Host page
+ * buffers must stay valid until the batch's focr_pipe_wait returns.  wait and
+ * release may be called from a different thread than submit. */
+typedef struct focr_pipe focr_pipe_t;
+int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out);
+void focr_pipe_destroy(focr_pipe_t *pipe);
+unsigned focr_pipe_contexts(const focr_pipe_t *pipe);
+focr_ctx_t *focr_pipe_context(focr_pipe_t *pipe, unsigned index);
+int focr_pipe_bank_upload(focr_pipe_t *pipe, const focr_template_t *templates, size_t n_templates,
+                          const uint8_t *needles, size_t needles_len);
+/* One batch = pages (host luma8 or, with pages_on_device != 0, a device
+ * pointer; NULL = resident) -> focr_scan(threshold, cap, mode) -> if
+ * process_hits != 0, focr_process_hits(anchor_threshold, overlap).  If
+ * chars_out != NULL (a device buffer of chars_out_bytes) the batch's
+ * characters (focr_hit_t[focr_total_chars]) are also copied there on the
+ * context's stream before the batch completes, so that the caller can release
+ * the lane at once and still hand the characters to a collective;
+ * FOCR_ERR_OVERFLOW if they do not fit. */
+int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, size_t n_pages, size_t r_w,
+                     size_t r_h, int invert, float threshold, uint32_t cap, int mode, int process_hits,
+                     float anchor_threshold, int32_t overlap, void *chars_out, size_t chars_out_bytes,
+                     uint64_t *ticket);
+/* Blocks until the batch is done; returns its status and the context that
+ * holds its results (all getters of this header apply). */
+int focr_pipe_wait(focr_pipe_t *pipe, uint64_t ticket, focr_ctx_t **ctx);
+/* The lane may take its next batch; the results of `ticket` are gone. */
+int focr_pipe_release(focr_pipe_t *pipe, uint64_t ticket);
+
 /* Per-launch record of the scan kernels of the last focr_scan (one entry per
  * (size class, bank chunk) launch), timed with HIP events on the stream the
  * kernel ran on.  alg_macs: true template area x searched windows x templates

@@ -523,3 +523,44 @@ def test_extreme_page_geometry(scanner, bank_x2, mode, shape):
     assert sum(len(x) for x in want[0]) > 100
     with pytest.raises(Exception, match="65535"):
         scanner.alloc_pages(1, 65536, 20)
+
+
+def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
+    """focr_pipe_*: the native batches-in-flight executor — tickets complete in order, each batch's lists equal the
+    oracle's, host and resident submissions both work, misuse is reported."""
+    from font_ocr_amd.searcher import FocrError, Pipeline
+
+    n_batches = 7
+    pages = [np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 1200 + 2 * b + p, 280 + 8 * (b % 3), 96) for p in range(2)])
+             for b in range(n_batches)]
+    want = [_oracle_lists(pg, bank_x2, 0.8, 1024) for pg in pages]
+    pipe = Pipeline(0, 3)
+    try:
+        pipe.set_bank(bank_x2)
+        tickets = []
+        for b in range(n_batches):
+            if len(tickets) >= 3:
+                t = tickets[b - 3]
+                sc = pipe.wait(t)
+                offsets, m = sc.matches()
+                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - 3], f"batch {b - 3}")
+                assert sc.total_chars() > 0
+                pipe.release(t)
+            tickets.append(pipe.submit(pages[b], 0.8))
+        assert tickets == list(range(1, n_batches + 1))
+        for b in range(n_batches - 3, n_batches):
+            sc = pipe.wait(tickets[b])
+            offsets, m = sc.matches()
+            _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"batch {b}")
+            pipe.release(tickets[b])
+        # resident rescan: ticket 8 maps to lane (8 - 1) % 3 = 1, which last held ticket 5 = batch 4
+        t = pipe.submit(None, 0.8)
+        assert t == 8
+        sc = pipe.wait(t)
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[4], "resident rescan")
+        pipe.release(t)
+        with pytest.raises(FocrError):
+            pipe.release(t)  # already released
+    finally:
+        pipe.close()
