@@ -564,3 +564,54 @@ def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
             pipe.release(t)  # already released
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_process_hits_ties_and_group_anchoring(scanner, bank_x2, mode):
+    """process_hits corner semantics (src/ncc.rs:755-764, 1042-1048): exact similarity ties (duplicated templates score
+    the same on the same window -> `max_by` keeps the LAST maximum, i.e. the later template), groups anchored on their
+    first element (a chain of hits each within `overlap` of its neighbour but not of the group's first splits), and
+    an anchor threshold that only some lines reach."""
+    base = [t for t in range(len(bank_x2)) if int(bank_x2.templates[t]["shift_x"]) == 0][1:40]  # shift-0 glyphs, no space
+    idx = base + base[:10] + base[:5]  # duplicates: templates len(base)+k == k, and a third copy of the first five
+    bank = bank_x2.subset(idx)
+    letters = bank.templates["letter"].copy()
+    letters[len(base):] += 1000  # make the copies distinguishable in the output
+    bank.templates["letter"] = letters
+    n_w, n_h = int(bank.templates[0]["n_w"]), int(bank.templates[0]["n_h"])
+    rng = np.random.default_rng(11)
+    ink = np.zeros((3, 130, 420), np.uint32)
+    for p in range(3):
+        for li in range(4):
+            x = 10
+            while x + n_w < 400:
+                t = int(rng.integers(0, len(base)))
+                y = 8 + 30 * li
+                nd = bank.needle(t).astype(np.uint32)
+                if li == 3:
+                    nd = nd // 2 + (rng.integers(0, 40, nd.shape)).astype(np.uint32)  # faint, noisy line: below the anchor
+                ink[p, y:y + n_h, x:x + n_w] += nd
+                x += int(rng.choice([3, 4, 6, 8, 9]))  # dense chains of overlapping stamps -> long partition_by chains
+    pages = (255 - np.minimum(ink, 255)).astype(np.uint8)
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    scanner.scan(0.5, 1024, mode)
+    offsets, m = scanner.matches()
+    got = _csr_to_lists(offsets, m, 3, len(bank))
+    n_ties = 0
+    for anchor, overlap in [(0.95, 5), (0.8, 3), (0.999, 9), (0.6, 0)]:
+        scanner.process_hits(anchor, overlap)
+        lines = scanner.lines()
+        for p in range(3):
+            counts = np.array([len(x) for x in got[p]], np.uint32)
+            mm = np.zeros((len(bank), 1024), O.MATCH_DTYPE)
+            for t, x in enumerate(got[p]):
+                mm[t, : len(x)] = x
+            want = O.process_hits(O.raw_hits(counts, mm, bank), anchor, overlap)
+            assert len(lines[p]) == len(want), (p, anchor, overlap)
+            for lg, lw in zip(lines[p], want):
+                assert np.array_equal(lg["x"], lw["x"]) and np.array_equal(lg["y"], lw["y"])
+                assert np.array_equal(lg["letter"], lw["letter"])
+                assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
+                n_ties += int((lg["letter"] >= 1000).sum())
+    assert n_ties > 20  # the later copy won its ties
