@@ -6,6 +6,11 @@ lazily and loudly — there is no CPU fallback for the scan.
 import ctypes as C
 import os
 
+# Several contexts (focr_pipe_*) mean several streams; ROCm maps a process's streams onto 4 hardware queues by
+# default and a small copy sharing a queue with a context waits behind its scan kernel.
+# Only effective if the HIP runtime has not initialised yet; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
