@@ -5,8 +5,8 @@
 //   * the template bank is rasterised once per run, not once per page (src/ncc.rs:561, 587-639);
 //   * pages of equal size are scanned as one device batch instead of one rayon task per page
 //     (src/ncc.rs:839-847); output order is still the order of -i;
-//   * --rust selects the exact v_dot4 device path (FOCR_SCAN_DIRECT) instead of the reference's scalar
-//     Rust scan (src/ncc.rs:406-483) — both are "the other implementation" used for A/B checks;
+//   * --rust runs the exact v_dot4 device kernel with the arithmetic and skips of the reference's scalar Rust
+//     scan and without the 1024 cap (FOCR_SCAN_RUST; src/ncc.rs:320-330, 406-483);
 //   * a page without any hit prints nothing (the reference panics in partition_by, src/ncc.rs:1040).
 #include <algorithm>
 #include <atomic>
@@ -354,7 +354,9 @@ int main(int argc, char **argv) {
         if (focr_bank_upload(ctxs[j], bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
             fatal(std::string("focr_bank_upload: ") + focr_last_error(ctxs[j]));
     }
-    const int mode = args.rust ? FOCR_SCAN_DIRECT : FOCR_SCAN_MFMA;
+    // --rust: the scalar scan's arithmetic and its missing cap (src/ncc.rs:320-330, 406-483) on the exact device kernel
+    const int mode = args.rust ? FOCR_SCAN_RUST : FOCR_SCAN_MFMA;
+    const uint32_t cap = args.rust ? 0xffffffffu : (uint32_t)FOCR_MAX_MATCHES;
     clk.lap("ctx + bank");
 
     const size_t T = bank.n_templates;
@@ -393,13 +395,13 @@ int main(int argc, char **argv) {
             for (size_t k = 0; k < idx.size(); k++) CKB(focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
             r.ms_upload += since(t0);
             t0 = now();
-            CKB(focr_scan(ctx, args.threshold, FOCR_MAX_MATCHES, mode));
+            CKB(focr_scan(ctx, args.threshold, cap, mode));
             r.ms_scan += since(t0);
             t0 = now();
             std::vector<uint32_t> counts(idx.size() * T);
             CKB(focr_get_counts(ctx, counts.data()));
             for (uint32_t cnt : counts)
-                if (cnt == FOCR_MAX_MATCHES) r.log += "WARN got >= " + std::to_string(FOCR_MAX_MATCHES) + " matches\n";  // src/ncc.rs:395-397
+                if (!args.rust && cnt == FOCR_MAX_MATCHES) r.log += "WARN got >= " + std::to_string(FOCR_MAX_MATCHES) + " matches\n";  // src/ncc.rs:395-397
             if (args.verbose) {
                 float ms[6];
                 focr_last_timings(ctx, ms);

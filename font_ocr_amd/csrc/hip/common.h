@@ -50,6 +50,7 @@ struct TemplateConst {
     double s_n;      // (double)s_n
     double n_recip;  // 1 / n
     double rnorm_n;  // 1 / sqrt(norm2_n)   (+inf for a constant needle)
+    double norm2_n;  // s2_n - s_n^2 / n, for the scalar Rust scan's formula (src/ncc.rs:455)
     uint32_t index;  // global template index (get_hits order)
     uint32_t n_w, n_h;
     uint32_t pad;
@@ -181,7 +182,7 @@ int fail(focr_ctx *ctx, int code, const std::string &msg);
     } while (0)
 
 // launchers implemented in the .hip files
-int launch_scan_direct(focr_ctx *ctx, float threshold);
+int launch_scan_direct(focr_ctx *ctx, float threshold, int rust_formula);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
@@ -203,6 +204,18 @@ __device__ __forceinline__ double ncc_similarity(uint32_t acc, uint32_t s_p, dou
     double num = __builtin_fma(-(s_n_d * (double)(int32_t)s_p), n_recip, (double)(int32_t)acc);
     double den = rnorm_n * rnorm_p;
     return num * den;
+}
+
+// The scalar Rust scan's arithmetic and skips (`ncc --rust`, src/ncc.rs:431-433, 445-470): returns "emits".
+__device__ __forceinline__ bool rust_similarity(uint32_t acc, uint32_t s_p, uint64_t s2_p, double s_n_d, double norm2_n,
+                                                double n_d, double thr_d, double *sim) {
+    if (s_n_d == 0.0 || s_p == 0) return false;                                          // :431-433, :447-449
+    const double num = (double)acc - (double)((uint64_t)s_n_d * (uint64_t)s_p) / n_d;    // :450
+    if (num < 0.) return false;                                                          // :451-453
+    const double norm2_p = (double)s2_p - (double)((uint64_t)s_p * (uint64_t)s_p) / n_d;  // :456
+    const double den = __builtin_sqrt(norm2_n * norm2_p);                                // :459
+    *sim = num / den;                                                                    // :460
+    return !(*sim == __builtin_inf()) && *sim > thr_d;                                   // :466
 }
 
 // emit test, src/ncc.cpp:362-366: (sim > thr) && !(sim == +inf); NaN fails both compares.

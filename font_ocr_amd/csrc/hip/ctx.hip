@@ -332,6 +332,7 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
             tc.s_n = (double)s_n;
             tc.n_recip = 1. / (double)n;
             tc.rnorm_n = 1. / std::sqrt(norm2_n);
+            tc.norm2_n = norm2_n;
             tc.index = t;
             tc.n_w = sc.n_w;
             tc.n_h = sc.n_h;
@@ -546,7 +547,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     if (!c->n_templates) return fail(c, FOCR_ERR_STATE, "focr_scan: no bank uploaded");
     if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_scan: no pages resident");
     if (cap == 0) return fail(c, FOCR_ERR_INVALID, "focr_scan: cap must be >= 1 (src/ncc.cpp:43-46)");
-    if (mode != FOCR_SCAN_MFMA && mode != FOCR_SCAN_DIRECT) return fail(c, FOCR_ERR_INVALID, "focr_scan: bad mode");
+    if (mode != FOCR_SCAN_MFMA && mode != FOCR_SCAN_DIRECT && mode != FOCR_SCAN_RUST) return fail(c, FOCR_ERR_INVALID, "focr_scan: bad mode");
     if (std::isnan(threshold)) threshold = INFINITY;  // `sim > NaN` is never true in the reference (src/ncc.cpp:362-366): no hits
     FOCR_HIP(c, hipSetDevice(c->device));
     c->cap = cap;
@@ -571,7 +572,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         c->sub_p0 = p0;
         c->sub_np = np;
         c->ordered = false;
-        int r = mode == FOCR_SCAN_DIRECT ? launch_scan_direct(c, threshold) : launch_scan_mfma(c, threshold);
+        int r = mode == FOCR_SCAN_MFMA ? launch_scan_mfma(c, threshold) : launch_scan_direct(c, threshold, mode == FOCR_SCAN_RUST);
         if (r) return r;
         return c->ordered ? FOCR_OK : order_hits(c);
     };

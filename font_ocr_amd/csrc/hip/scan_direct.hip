@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
                                                           const TemplateConst *__restrict__ tc, uint32_t n_class,
                                                           KeyFmt fmt, double thr_d, uint64_t *__restrict__ hit_keys,
                                                           float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
-                                                          unsigned long long capacity, uint32_t page_base) {
+                                                          unsigned long long capacity, uint32_t page_base, int rust) {
     constexpr int LROWS = DTY + MAXH - 1;
     __shared__ uint32_t tile[LROWS][DLDW];
     const uint32_t page = page_base + blockIdx.z;
@@ -72,8 +72,15 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(const uint8_t *__restr
 #pragma unroll
             for (int k = 0; k < NDW; k++) acc = __builtin_amdgcn_udot4(win[j][k], tp[j * NDW + k], acc, false);
         const double s_n = tc[t].s_n, n_recip = tc[t].n_recip, rnorm_n = tc[t].rnorm_n;
-        const double sim = ncc_similarity(acc, s_p, s_n, n_recip, rnorm_n, rnorm_p);
-        if (valid && ncc_emits(sim, thr_d)) {
+        double sim;
+        bool emits;
+        if (rust) {
+            emits = rust_similarity(acc, s_p, (uint64_t)s2_p, s_n, tc[t].norm2_n, (double)(n_w * n_h), thr_d, &sim);
+        } else {
+            sim = ncc_similarity(acc, s_p, s_n, n_recip, rnorm_n, rnorm_p);
+            emits = ncc_emits(sim, thr_d);
+        }
+        if (valid && emits) {
             unsigned long long idx = atomicAdd(counter, 1ull);
             if (idx < capacity) {
                 hit_keys[idx] = fmt.pack(page, y, x, tc[t].index);
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void scan_tall_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ bank, const TemplateConst *__restrict__ tc,
                                                         uint32_t n_class, KeyFmt fmt, double thr_d, uint64_t *__restrict__ hit_keys,
                                                         float *__restrict__ hit_sims, unsigned long long *__restrict__ counter,
-                                                        unsigned long long capacity, uint32_t page_base) {
+                                                        unsigned long long capacity, uint32_t page_base, int rust) {
     extern __shared__ uint32_t tall_tile[];  // [DTY + n_h - 1][DLDW]
     const uint32_t lrows = DTY + n_h - 1;
     const uint32_t page = page_base + blockIdx.z;
@@ -158,8 +165,15 @@ __global__ __launch_bounds__(256) void scan_tall_kernel(const uint8_t *__restric
         for (int u = 0; u < TALL_TC; u++) {
             const uint32_t t = t0 + u;
             if (t >= n_class) break;
-            const double sim = ncc_similarity(acc[u], s_p, tc[t].s_n, tc[t].n_recip, tc[t].rnorm_n, rnorm_p);
-            if (valid && ncc_emits(sim, thr_d)) {
+            double sim;
+            bool emits;
+            if (rust) {
+                emits = rust_similarity(acc[u], s_p, (uint64_t)s2_p, tc[t].s_n, tc[t].norm2_n, (double)(n_w * n_h), thr_d, &sim);
+            } else {
+                sim = ncc_similarity(acc[u], s_p, tc[t].s_n, tc[t].n_recip, tc[t].rnorm_n, rnorm_p);
+                emits = ncc_emits(sim, thr_d);
+            }
+            if (valid && emits) {
                 unsigned long long idx = atomicAdd(counter, 1ull);
                 if (idx < capacity) {
                     hit_keys[idx] = fmt.pack(page, y, x, tc[t].index);
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void scan_tall_kernel(const uint8_t *__restric
 
 template <int NDW>
 static void launch_tall_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d, uint64_t *keys, float *sims,
-                            unsigned long long *counter, unsigned long long capacity) {
+                            unsigned long long *counter, unsigned long long capacity, int rust) {
     dim3 grid((unsigned)((c->r_w - sc.n_w + DTX - 1) / DTX), (unsigned)((c->r_h - sc.n_h + DTY - 1) / DTY), (unsigned)c->sub_np);
     const uint64_t win = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * c->sub_np;
     char name[64];
@@ -182,23 +196,23 @@ static void launch_tall_one(focr_ctx *c, const SizeClass &sc, size_t k, double t
     hipLaunchKernelGGL((scan_tall_kernel<NDW>), grid, dim3(256), lds, c->stream, c->d_pages, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
                        c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates, c->fmt, thr_d, keys, sims,
-                       counter, capacity, (uint32_t)c->sub_p0);
+                       counter, capacity, (uint32_t)c->sub_p0, rust);
     c->launch_end();
 }
 
 // Scan one tall class (both modes call this).  sims == nullptr: keys only.
 int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float *sims, unsigned long long *counter,
-                     unsigned long long capacity) {
+                     unsigned long long capacity, int rust) {
     const SizeClass &sc = c->classes[k];
     switch (sc.ndw) {
-        case 1: launch_tall_one<1>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 2: launch_tall_one<2>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 3: launch_tall_one<3>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 4: launch_tall_one<4>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 5: launch_tall_one<5>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 6: launch_tall_one<6>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 7: launch_tall_one<7>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
-        case 8: launch_tall_one<8>(c, sc, k, thr_d, keys, sims, counter, capacity); break;
+        case 1: launch_tall_one<1>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 2: launch_tall_one<2>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 3: launch_tall_one<3>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 4: launch_tall_one<4>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 5: launch_tall_one<5>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 6: launch_tall_one<6>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 7: launch_tall_one<7>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
+        case 8: launch_tall_one<8>(c, sc, k, thr_d, keys, sims, counter, capacity, rust); break;
         default: return fail(c, FOCR_ERR_INVALID, "scan_tall: unsupported size class");
     }
     FOCR_HIP(c, hipGetLastError());
@@ -207,7 +221,7 @@ int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float 
 }
 
 template <int NDW, int MAXH>
-static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d) {
+static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d, int rust) {
     dim3 grid((unsigned)((c->r_w - sc.n_w + DTX - 1) / DTX), (unsigned)((c->r_h - sc.n_h + DTY - 1) / DTY),
               (unsigned)c->sub_np);
     const uint64_t win = (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * c->sub_np;
@@ -218,7 +232,7 @@ static void launch_one(focr_ctx *c, const SizeClass &sc, size_t k, double thr_d)
                        (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h,
                        c->d_direct_bank + c->direct_bank_off[k], c->d_tconst + sc.first, sc.n_templates,
                        c->fmt, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
-                       (unsigned long long)c->hit_capacity, (uint32_t)c->sub_p0);
+                       (unsigned long long)c->hit_capacity, (uint32_t)c->sub_p0, rust);
     c->launch_end();
 }
 
@@ -238,7 +252,7 @@ int ensure_hit_capacity(focr_ctx *c, size_t want) {
     return FOCR_OK;
 }
 
-int launch_scan_direct(focr_ctx *c, float threshold) {
+int launch_scan_direct(focr_ctx *c, float threshold, int rust) {
     const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
     int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
@@ -252,19 +266,19 @@ int launch_scan_direct(focr_ctx *c, float threshold) {
             if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;  // no window with x,y >= 1 fits
             if (sc.tall) {
                 if ((rc = launch_scan_tall(c, k, thr_d, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
-                                           (unsigned long long)c->hit_capacity)))
+                                           (unsigned long long)c->hit_capacity, rust)))
                     return rc;
                 continue;
             }
             switch (sc.ndw * 100 + sc.maxh) {
-                case 116: launch_one<1, 16>(c, sc, k, thr_d); break;
-                case 216: launch_one<2, 16>(c, sc, k, thr_d); break;
-                case 316: launch_one<3, 16>(c, sc, k, thr_d); break;
-                case 416: launch_one<4, 16>(c, sc, k, thr_d); break;
-                case 132: launch_one<1, 32>(c, sc, k, thr_d); break;
-                case 232: launch_one<2, 32>(c, sc, k, thr_d); break;
-                case 332: launch_one<3, 32>(c, sc, k, thr_d); break;
-                case 432: launch_one<4, 32>(c, sc, k, thr_d); break;
+                case 116: launch_one<1, 16>(c, sc, k, thr_d, rust); break;
+                case 216: launch_one<2, 16>(c, sc, k, thr_d, rust); break;
+                case 316: launch_one<3, 16>(c, sc, k, thr_d, rust); break;
+                case 416: launch_one<4, 16>(c, sc, k, thr_d, rust); break;
+                case 132: launch_one<1, 32>(c, sc, k, thr_d, rust); break;
+                case 232: launch_one<2, 32>(c, sc, k, thr_d, rust); break;
+                case 332: launch_one<3, 32>(c, sc, k, thr_d, rust); break;
+                case 432: launch_one<4, 32>(c, sc, k, thr_d, rust); break;
                 default: return fail(c, FOCR_ERR_INVALID, "scan_direct: unsupported size class");
             }
             FOCR_HIP(c, hipGetLastError());

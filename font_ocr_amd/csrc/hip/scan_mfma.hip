@@ -34,7 +34,7 @@ namespace focr {
 int ensure_hit_capacity(focr_ctx *c, size_t want);
 int sort_keys_u64(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned end_bit);
 int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float *sims, unsigned long long *counter,
-                     unsigned long long capacity);
+                     unsigned long long capacity, int rust);
 int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos, size_t n);
 
 
@@ -570,7 +570,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const SizeClass &sc = c->classes[k];
             if (!sc.tall || sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
             if ((rc = launch_scan_tall(c, k, thr_d, c->d_cand, nullptr, (unsigned long long *)c->d_counter + 1,
-                                       (unsigned long long)c->cand_capacity)))
+                                       (unsigned long long)c->cand_capacity, 0)))
                 return rc;
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));

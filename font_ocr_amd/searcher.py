@@ -14,7 +14,7 @@ from . import _native as N
 from .bank import HIT_DTYPE, MATCH_DTYPE
 
 MAX_MATCHES = 1024  # src/ncc.rs:31
-SCAN_MFMA, SCAN_DIRECT = 0, 1
+SCAN_MFMA, SCAN_DIRECT, SCAN_RUST = 0, 1, 2
 
 
 class FocrError(RuntimeError):

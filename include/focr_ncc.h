@@ -106,7 +106,12 @@ typedef struct focr_template {
 /* Which device formulation scans the bank.  Both give identical results. */
 enum {
     FOCR_SCAN_MFMA = 0,   /* i8 MFMA conservative prefilter + exact verify (default, fast) */
-    FOCR_SCAN_DIRECT = 1  /* exact v_dot4 evaluation of every (window, template) */
+    FOCR_SCAN_DIRECT = 1, /* exact v_dot4 evaluation of every (window, template) */
+    FOCR_SCAN_RUST = 2    /* same kernel with the arithmetic of the reference's scalar Rust scan
+                           * (`ncc --rust`, src/ncc.rs:406-483): num = acc - s_n*s_p/n (a division),
+                           * sim = num / sqrt(norm2_n * norm2_p), windows with s_p == 0 or num < 0
+                           * are skipped, templates with s_n == 0 yield nothing; that path has no
+                           * 1024 cap (pass cap = UINT32_MAX) */
 };
 
 /* One raw or post-processed hit with its template, as MatchWithLetter

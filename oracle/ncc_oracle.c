@@ -218,6 +218,55 @@ size_t oracle_ncc_u8(const uint8_t *reference, size_t r_w, size_t r_h, const uin
     return cnt;
 }
 
+/* Searcher::search_n_u8, src/ncc.rs:406-483 — the scalar scan behind `ncc --rust`.
+ * Same windows and the same integer dot product as the AVX2 path, but
+ *   num = acc - (s_n * s_p) / n            (a division, :450; windows with s_p == 0 or num < 0 are skipped, :447-453)
+ *   sim = num / sqrt(norm2_n * norm2_p)    (:455-460)
+ *   emit iff sim != +inf && sim > thr      (:466), similarity narrowed to f32 (:461)
+ * a needle with s_n == 0 yields nothing (:431-433) and there is no cap on the number of matches (a Vec).
+ * `cap` here only bounds the output buffer; returns the number of matches found (may exceed cap: the caller sized
+ * the buffer too small).  Parity-unpinned: no Rust toolchain here, restated from the text. */
+size_t oracle_search_rust_u8(const uint8_t *reference, size_t r_w, size_t r_h, const uint8_t *needle,
+                             size_t n_w, size_t n_h, const uint32_t *sum_table, const uint64_t *sumsqr_table,
+                             const uint16_t *start_end, float threshold, OracleMatch *out, size_t cap) {
+    size_t n = n_w * n_h, cnt = 0;
+    if (r_h < n_h || r_w < n_w) return 0;
+    size_t y_searches = r_h - n_h + 1;
+    uint32_t s_n = 0, s2_n = 0; /* image_sum_sumsqr over the dense needle */
+    for (size_t i = 0; i < n; i++) {
+        s_n += needle[i];
+        s2_n += (uint32_t)needle[i] * (uint32_t)needle[i];
+    }
+    if (s_n == 0) return 0;
+    for (size_t y = 1; y < y_searches; y++) {
+        size_t start = start_end[y * 2 + 0], end = start_end[y * 2 + 1];
+        for (size_t x = start; x < end; x++) {
+            uint32_t acc = 0;
+            for (size_t j = 0; j < n_h; j++)
+                for (size_t i = 0; i < n_w; i++)
+                    acc += (uint32_t)needle[j * n_w + i] * (uint32_t)reference[(y + j) * r_w + x + i];
+            uint32_t s_p = sum_nz(sum_table, r_w, x, y, n_w, n_h);
+            uint64_t s2_p = sumsqr_nz(sumsqr_table, r_w, x, y, n_w, n_h);
+            if (s_p == 0) continue;
+            double num = (double)acc - (double)((uint64_t)s_n * (uint64_t)s_p) / (double)n;
+            if (num < 0.) continue;
+            double norm2_n = (double)s2_n - (double)((uint64_t)s_n * (uint64_t)s_n) / (double)n;
+            double norm2_p = (double)s2_p - (double)((uint64_t)s_p * (uint64_t)s_p) / (double)n;
+            double den = sqrt(norm2_n * norm2_p);
+            double sim = num / den;
+            if (sim != INFINITY && sim > (double)threshold) {
+                if (cnt < cap) {
+                    out[cnt].x = (uint16_t)x;
+                    out[cnt].y = (uint16_t)y;
+                    out[cnt].similarity = (float)sim;
+                }
+                cnt++;
+            }
+        }
+    }
+    return cnt;
+}
+
 /* ---- process_hits: src/ncc.rs:723-786 + partition_by 1036-1052 --------- */
 
 static inline int32_t f32_total_key(float f) { /* f32::total_cmp ordering key */
@@ -364,6 +413,42 @@ size_t oracle_scan_page(const uint8_t *page, size_t r_w, size_t r_h, const uint8
     free(patch_rnorm);
     free(start_end);
     free(acc);
+    return total;
+}
+
+/* get_hits' loop with search_u8 (`--rust`, src/ncc.rs:320-330, 650-654): as oracle_scan_page, scalar arithmetic,
+ * no cap semantics (counts[t] may exceed `cap`, only the first `cap` matches are stored). */
+size_t oracle_scan_page_rust(const uint8_t *page, size_t r_w, size_t r_h, const uint8_t *needles,
+                             const OracleTemplate *tmpl, size_t n_templates, float threshold, size_t cap,
+                             uint32_t *counts, OracleMatch *matches) {
+    size_t npx = r_w * r_h;
+    uint32_t *sum_table = (uint32_t *)malloc(npx * 4);
+    uint64_t *sumsqr_table = (uint64_t *)malloc(npx * 8);
+    uint32_t *patch_sum = (uint32_t *)calloc(npx, 4);
+    double *patch_rnorm = (double *)calloc(npx, 8);
+    uint16_t *start_end = (uint16_t *)calloc(r_h * 2, 2);
+    oracle_sum_table(page, r_w, r_h, sum_table);
+    oracle_sumsqr_table(page, r_w, r_h, sumsqr_table);
+    size_t last_w = 0, last_h = 0, total = 0;
+    for (size_t t = 0; t < n_templates; t++) {
+        size_t n_w = tmpl[t].n_w, n_h = tmpl[t].n_h;
+        counts[t] = 0;
+        if (n_w == 0 || n_h == 0 || n_w > 16 || n_w > r_w || n_h > r_h) continue; /* todo!() above 16, src/ncc.rs:328 */
+        if (n_w != last_w || n_h != last_h) {
+            oracle_prepare_for_size(sum_table, sumsqr_table, r_w, r_h, n_w, n_h, patch_sum, patch_rnorm, start_end);
+            last_w = n_w;
+            last_h = n_h;
+        }
+        size_t c = oracle_search_rust_u8(page, r_w, r_h, needles + tmpl[t].offset, n_w, n_h, sum_table, sumsqr_table,
+                                         start_end, threshold, matches + t * cap, cap);
+        counts[t] = (uint32_t)c;
+        total += c;
+    }
+    free(sum_table);
+    free(sumsqr_table);
+    free(patch_sum);
+    free(patch_rnorm);
+    free(start_end);
     return total;
 }
 

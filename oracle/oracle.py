@@ -51,6 +51,9 @@ def lib():
         L.oracle_scan_page.restype = C.c_size_t
         L.oracle_scan_page.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                        C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_scan_page_rust.restype = C.c_size_t
+        L.oracle_scan_page_rust.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                                            C.c_size_t, C.c_void_p, C.c_void_p]
         L.oracle_scan_pages_mt.restype = C.c_size_t
         L.oracle_scan_pages_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_float, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
@@ -170,6 +173,19 @@ def scan_page(page_inv, bank, threshold, cap=1024, use_ref=False):
     k8, k16 = _kernel_ptrs(use_ref)
     lib().oracle_scan_page(flat.ctypes.data, r_w, r_h, needles.ctypes.data, tm.ctypes.data, len(tm), threshold, cap,
                            k8, k16, counts.ctypes.data, matches.ctypes.data)
+    return counts, matches
+
+
+def scan_page_rust(page_inv, bank, threshold, cap=1 << 16):
+    """get_hits' loop through the scalar Rust scan (`ncc --rust`, src/ncc.rs:320-330, 406-483): no cap semantics —
+    counts[t] is the full number of matches, matches holds the first `cap` of each template."""
+    r_h, r_w = page_inv.shape
+    flat = padded(page_inv)
+    tm, needles = _bank_arrays(bank)
+    counts = np.zeros(len(tm), np.uint32)
+    matches = np.zeros((len(tm), cap), MATCH_DTYPE)
+    lib().oracle_scan_page_rust(flat.ctypes.data, r_w, r_h, needles.ctypes.data, tm.ctypes.data, len(tm), threshold, cap,
+                                counts.ctypes.data, matches.ctypes.data)
     return counts, matches
 
 

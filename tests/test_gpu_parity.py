@@ -615,3 +615,36 @@ def test_process_hits_ties_and_group_anchoring(scanner, bank_x2, mode):
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
                 n_ties += int((lg["letter"] >= 1000).sum())
     assert n_ties > 20  # the later copy won its ties
+
+
+@pytest.mark.parametrize("thr", [0.8, 0.3, -0.5])
+def test_rust_scan_mode_vs_oracle(scanner, bank_x2, thr):
+    """FOCR_SCAN_RUST (`ncc --rust`): the scalar scan's arithmetic (division instead of fma,
+    sqrt of the norm product), its skips (s_p == 0, num < 0, s_n == 0) and its missing cap, against the oracle's
+    restatement of src/ncc.rs:406-483 — positions exact, similarities bit-identical."""
+    from font_ocr_amd.searcher import SCAN_RUST
+
+    pages = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 1300 + p, 250, 90) for p in range(2)])
+    pages[1, 40:, 120:] = np.random.default_rng(3).integers(0, 256, (50, 130), dtype=np.uint8)  # noise: many low-sim hits
+    scanner.set_bank(bank_x2)
+    scanner.set_pages(pages)
+    cap = 0xFFFFFFFF
+    scanner.scan(thr, cap, SCAN_RUST)
+    counts = scanner.counts()
+    offsets, m = scanner.matches()
+    T = len(bank_x2)
+    big = 1 << 15
+    for p in range(2):
+        wc, wm = O.scan_page_rust(O.invert(pages[p]), bank_x2, thr, cap=big)
+        assert wc.max() < big
+        assert np.array_equal(counts[p], wc), (p, thr)
+        for t in range(T):
+            got = m[offsets[p * T + t]: offsets[p * T + t + 1]]
+            want = wm[t, : wc[t]]
+            assert got.tobytes() == want.tobytes(), (p, t, thr)
+    if thr < 0:
+        assert counts.max() > 1024  # more than the AVX2 path's cap: the Rust path has none
+    # and it differs from the C path where it should: negative numerators are skipped
+    if thr < 0:
+        scanner.scan(thr, cap, SCAN_DIRECT)
+        assert scanner.counts().sum() > counts.sum()
