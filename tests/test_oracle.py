@@ -156,3 +156,51 @@ def test_c2_golden_page_is_reproducible(bank_x2, c2_golden):
     page = synth_page(bank_x2, SYNTH_SEED_BASE, 608, 720)
     assert np.uint32(zlib.crc32(page.tobytes())) == c2_golden["page_crc"]
     assert int(c2_golden["counts"].sum()) == len(c2_golden["matches"])
+
+
+def test_rust_scan_restatement_vs_numpy_bruteforce():
+    """oracle_search_rust_u8 (src/ncc.rs:406-483, `ncc --rust`) against a direct numpy evaluation of the same formula
+    on a tiny page: skips (s_p == 0, num < 0), no cap, (y, x) order, x = 0 / y = 0 never searched."""
+    from font_ocr_amd.bank import TEMPLATE_DTYPE, Bank
+
+    rng = np.random.default_rng(21)
+    page = rng.integers(0, 256, (24, 31), dtype=np.uint8)
+    page[:, :6] = 0  # a blank margin: windows with s_p == 0
+    needles, tm, off = [], [], 0
+    for (w, h) in [(5, 7), (9, 4), (3, 3)]:
+        for k in range(3):
+            nd = rng.integers(0, 256, (h, w), dtype=np.uint8) if k else np.zeros((h, w), np.uint8)  # k == 0: s_n == 0
+            t = np.zeros(1, TEMPLATE_DTYPE)
+            t["n_w"], t["n_h"], t["offset"], t["letter"] = w, h, off, 65 + len(tm)
+            tm.append(t)
+            needles.append(nd.reshape(-1))
+            off += nd.size
+    bank = Bank(np.concatenate(tm), np.concatenate(needles), len(tm), 0, 0, 13.0, 8.0)
+    thr = -0.25
+    counts, matches = O.scan_page_rust(page, bank, thr, cap=4096)
+    for t in range(len(bank)):
+        nd = bank.needle(t).astype(np.int64)
+        h, w = nd.shape
+        n = float(h * w)
+        want = []
+        s_n, s2_n = int(nd.sum()), int((nd * nd).sum())
+        if s_n:
+            for y in range(1, 24 - h + 1):
+                for x in range(1, 31 - w + 1):
+                    win = page[y:y + h, x:x + w].astype(np.int64)
+                    s_p, s2_p, acc = int(win.sum()), int((win * win).sum()), int((win * nd).sum())
+                    if s_p == 0:
+                        continue
+                    num = float(acc) - float(s_n * s_p) / n
+                    if num < 0:
+                        continue
+                    den = np.sqrt((float(s2_n) - float(s_n * s_n) / n) * (float(s2_p) - float(s_p * s_p) / n))
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        sim = np.float64(num) / den
+                    if sim != np.inf and sim > np.float64(np.float32(thr)):
+                        want.append((x, y, np.float32(sim)))
+        got = matches[t, : counts[t]]
+        assert counts[t] == len(want), t
+        assert [(int(g["x"]), int(g["y"])) for g in got] == [(x, y) for x, y, _ in want]
+        assert np.array([s for _, _, s in want], np.float32).tobytes() == got["similarity"].tobytes()
+    assert counts.sum() > 100
