@@ -204,6 +204,87 @@ def test_full_size_c2_properties(scanner, bank_x2):
             ok += by_y.get(y) == want
             tot += 1
     assert ok >= 0.9 * tot, (ok, tot)
+    # every page's lists against the compiled reference kernel (oracle/_ref when present), not just page 0:
+    # the same 128 pages through get_hits' loop on the host cores, one page per thread (src/ncc.rs:839-847)
+    _assert_equal_ref_batch(res[SCAN_MFMA], pages, bank_x2, 0.8, 1024)
+
+
+def _host_threads():
+    import os
+
+    return max(1, min(len(os.sched_getaffinity(0)), 32))
+
+
+def _assert_equal_ref_batch(res, pages, bank, thr, cap):
+    """res = (counts[P][T], offsets, matches) of a device scan; compares counts and every (x, y, f32 bits) with the
+    CPU scan of the same pages (reference kernel where oracle/_ref exists, else the restatement)."""
+    counts, offsets, m = res
+    P, T = counts.shape
+    total, wc, wm = O.scan_pages_mt(O.invert(pages), bank, thr, cap, use_ref=O.have_ref(), threads=_host_threads(), keep_matches=True)
+    assert np.array_equal(counts, wc), f"counts differ on pages {sorted(set(np.nonzero(counts != wc)[0].tolist()))[:8]}"
+    assert int(total) == int(wc.sum()) == len(m)
+    flat = wm[np.arange(cap)[None, None, :] < wc[:, :, None]]  # (page, template, y, x) order == the device's CSR order
+    assert flat.tobytes() == m.tobytes()
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(wc.reshape(-1), dtype=np.uint64)]))
+
+
+def test_c3_geometry_1200x1600_vs_reference(scanner, bank_x2y2):
+    """BASELINE configs[2] at its own geometry: 1200x1600 pages, 95 glyphs x --x-bits 2 --y-bits 2 = 1520 templates in
+    four size classes.  Four pages are checked list for list against the reference kernel (src/ncc.cpp:253-396 through
+    get_hits' loop, ~35 s of one host core per page), both device formulations; then a 64-page batch goes through the
+    MFMA and the direct path, which must agree on every list, and the four checked pages must come out of the
+    big batch unchanged (a page's lists do not depend on its neighbours)."""
+    r_w, r_h = 1200, 1600
+    pages = synth_pages(bank_x2y2, 4, r_w, r_h, first=3000)
+    scanner.set_bank(bank_x2y2)
+    scanner.set_pages(pages)
+    scanner.scan(0.8, 1024, SCAN_MFMA)
+    res4 = (scanner.counts().copy(),) + scanner.matches()
+    _assert_equal_ref_batch(res4, pages, bank_x2y2, 0.8, 1024)
+    assert res4[0].sum() > 400_000  # dense text: ~1e5 raw hits per page
+    scanner.scan(0.8, 1024, SCAN_DIRECT)
+    assert np.array_equal(scanner.counts(), res4[0]) and scanner.matches()[1].tobytes() == res4[2].tobytes()
+    scanner.process_hits(0.95, 5)
+    lines4 = scanner.lines_flat().copy()
+    # 64 pages, MFMA == direct; pages 0..3 of the batch are the four above
+    big = np.concatenate([pages, synth_pages(bank_x2y2, 60, r_w, r_h, first=3004)])
+    scanner.set_pages(big)
+    res = {}
+    for mode in (SCAN_MFMA, SCAN_DIRECT):
+        scanner.scan(0.8, 1024, mode)
+        res[mode] = (scanner.counts().copy(),) + scanner.matches()
+    assert np.array_equal(res[SCAN_MFMA][0], res[SCAN_DIRECT][0])
+    assert res[SCAN_MFMA][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
+    assert np.array_equal(res[SCAN_MFMA][0][:4], res4[0])
+    assert res[SCAN_MFMA][2][: len(res4[2])].tobytes() == res4[2].tobytes()
+    scanner.process_hits(0.95, 5)
+    assert scanner.lines_flat()[: len(lines4)].tobytes() == lines4.tobytes()
+    scanner.set_pages(np.full((1, 20, 20), 255, np.uint8))  # give the 1.5 GB of page + table memory back to smaller tests
+
+
+def test_c5_256_template_gemm_variant(scanner, bank_x2):
+    """BASELINE configs[4]: "template-bank-as-GEMM variant, 256-glyph bank, bf16 MFMA windows x templates".  Here the
+    GEMM operand type is int8 (v_mfma_i32_16x16x64_i8), not bf16: BASELINE's north_star leaves the MFMA form open
+    ("MFMA only if ... that wins on rocprof"), int8 has twice bf16's rate and — unlike bf16 accumulation in fp32 of
+    products up to 255*255*135 — keeps the prefilter's bound in exact integer arithmetic (scan_mfma.hip header);
+    every emitted match is re-evaluated with the reference's u8*u8->u32 + f64 arithmetic (src/ncc.cpp:316-321,
+    352-361).  256 templates = the 95 shift-0 glyphs (8x15) + 161 templates of shifts 1/4 and 1/2 (9x15): the GEMM
+    formulation (MFMA), the v_dot4 formulation (direct) and the reference kernel must produce identical lists."""
+    bank = bank_x2.subset(range(256))
+    assert len({(int(t["n_w"]), int(t["n_h"])) for t in bank.templates}) == 2
+    pages = synth_pages(bank_x2, 8, 608, 720, first=5000)
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    res = {}
+    for mode in (SCAN_MFMA, SCAN_DIRECT):
+        scanner.scan(0.8, 1024, mode)
+        res[mode] = (scanner.counts().copy(),) + scanner.matches()
+        names = [li["name"] for li in scanner.launches()]
+        assert any(n.startswith("scan_mfma2") for n in names) == (mode == SCAN_MFMA), names
+    assert np.array_equal(res[SCAN_MFMA][0], res[SCAN_DIRECT][0])
+    assert res[SCAN_MFMA][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
+    _assert_equal_ref_batch(res[SCAN_MFMA], pages, bank, 0.8, 1024)
+    assert res[SCAN_MFMA][0].sum() > 50_000
 
 
 def _random_bank(rng, shapes, per_shape):

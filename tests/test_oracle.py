@@ -204,3 +204,88 @@ def test_rust_scan_restatement_vs_numpy_bruteforce():
         assert [(int(g["x"]), int(g["y"])) for g in got] == [(x, y) for x, y, _ in want]
         assert np.array([s for _, _, s in want], np.float32).tobytes() == got["similarity"].tobytes()
     assert counts.sum() > 100
+
+
+# ---- second witness for the Rust half (oracle/rust_witness.py: literal transliteration of src/ncc.rs) -------------
+
+def _witness_lines(hits, anchor, overlap):
+    from oracle import rust_witness as W
+
+    hs = [dict(x=int(h["x"]), y=int(h["y"]), similarity=float(h["similarity"]), i=i) for i, h in enumerate(hits)]
+    try:
+        return [[e["i"] for e in line] for line in W.process_hits(hs, anchor, overlap)]
+    except IndexError:  # no row reaches the anchor: the reference panics in partition_by (src/ncc.rs:747 -> 1040);
+        return []       # this build defines that case as "zero lines" 
+
+
+def _oracle_line_indices(hits, anchor, overlap):
+    """oracle_process_hits returns copies; recover which input hit each output is through a unique tag in `w`."""
+    tagged = hits.copy()
+    tagged["w"] = np.arange(len(hits))
+    return [[int(c["w"]) for c in line] for line in O.process_hits(tagged, anchor, overlap)]
+
+
+def test_rust_witness_process_hits_on_c1_golden(bank_default, c1_golden):
+    """Two independent readings of process_hits + partition_by (src/ncc.rs:723-786, 1036-1052) — the C restatement
+    and the literal Python transliteration — pick the same hit for every character of the configs[0] page."""
+    counts = c1_golden["counts"]
+    m = np.zeros((len(counts), 1024), O.MATCH_DTYPE)
+    off = 0
+    for t, c in enumerate(counts):
+        m[t, :c] = c1_golden["matches"][off:off + c]
+        off += c
+    hits = O.raw_hits(counts, m, bank_default)
+    for anchor, overlap in ((0.95, 5), (0.9, 2), (0.99, 9)):
+        assert _witness_lines(hits, anchor, overlap) == _oracle_line_indices(hits, anchor, overlap), (anchor, overlap)
+
+
+def test_rust_witness_process_hits_fuzz_with_ties():
+    """Fuzzed hit lists: few distinct similarities (many exact ties, signed zeros, a NaN and infinities for total_cmp),
+    dense x chains (anchored grouping), unsorted arrival order (stable sorts), anchors on some rows only."""
+    from oracle import rust_witness as W
+
+    rng = np.random.default_rng(77)
+    sims = np.array([0.5, 0.8, 0.95, 0.95, 0.97, 1.0, -0.0, 0.0, 0.9500001], np.float32)
+    for it in range(60):
+        n = int(rng.integers(1, 220))
+        hits = np.zeros(n, O.HIT_DTYPE)
+        hits["x"] = rng.integers(1, 60 if it % 2 else 400, n)
+        hits["y"] = rng.integers(1, 6, n) * (1 + it % 3)
+        hits["w"], hits["h"] = 8, 15
+        hits["similarity"] = sims[rng.integers(0, len(sims), n)]
+        hits["letter"] = rng.integers(33, 127, n)
+        if it % 7 == 0:
+            hits["similarity"][0] = np.float32("nan") if it % 14 == 0 else np.float32("inf")
+        overlap = int(rng.integers(0, 9))
+        anchor = float(rng.choice([0.95, 0.5, 0.97, 1.5]))
+        assert _witness_lines(hits, anchor, overlap) == _oracle_line_indices(hits, anchor, overlap), it
+    with pytest.raises(IndexError):  # the reference panics on an empty hit list (src/ncc.rs:1040)
+        W.partition_by([], lambda a, b: True)
+    assert W.partition_by([1, 2, 3, 9, 10, 14], lambda a, b: abs(a - b) <= 2) == [(0, 3), (3, 5), (5, 6)]
+    # anchored on the first element of a group, not on the previous one: 1,3,5 -> (1,3) then 5 opens a new group
+    assert W.partition_by([1, 3, 5], lambda a, b: abs(a - b) <= 2) == [(0, 2), (2, 3)]
+
+
+def test_rust_witness_prepare_for_size():
+    """prepare_for_size (src/ncc.rs:263-318) incl. the summed-area tables (938-974) and the 4-corner queries
+    (976-983, 1006-1013): C restatement == Python transliteration, bit for bit, on small pages with blank margins,
+    blank rows, saturated blocks (zero variance -> +inf) and noise."""
+    from oracle import rust_witness as W
+
+    rng = np.random.default_rng(5)
+    for it, (r_w, r_h, n_w, n_h) in enumerate([(40, 30, 9, 15), (33, 21, 8, 15), (25, 40, 3, 3), (18, 18, 16, 16), (30, 20, 1, 1)]):
+        page = np.zeros((r_h, r_w), np.uint8)
+        page[3:r_h - 4, 5:r_w - 6] = rng.integers(0, 256, (r_h - 7, r_w - 11))
+        page[6:9, :] = 0                # blank rows
+        page[10:16, 8:20] = 255         # saturated block: windows inside have zero variance
+        if it == 2:
+            page[:] = rng.integers(0, 256, page.shape)
+        ps, pr, se = O.prepare_for_size(page, n_w, n_h)
+        wps, wpr, wse = W.prepare_for_size(W.array2_from(page.tolist()), n_w, n_h)
+        assert list(se) == wse, it
+        for y in range(1, r_h - n_h + 1):
+            s, e = wse[2 * y], wse[2 * y + 1]
+            for x in range(s, e):
+                assert int(ps[y, x]) == wps[(x, y)], (it, x, y)
+                a, b = float(pr[y, x]), wpr[(x, y)]
+                assert (np.isnan(a) and np.isnan(b)) or np.float64(a).tobytes() == np.float64(b).tobytes(), (it, x, y, a, b)
