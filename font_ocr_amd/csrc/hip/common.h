@@ -31,6 +31,20 @@ struct SizeClass {
     uint32_t tg_offset;       // entry offset of the class's template ids in d_tglobal (16 per N-tile, ~0 = padding/dead)
 };
 
+// Two-stage prefilter data of one super-class (lowrank.hip builds it, scan_mfma3.hip uses it).
+constexpr uint32_t LR_K = 32;            // K of the stage-2 bf16 MFMA: r principal directions + R + N_F + one slot per class
+constexpr uint32_t LR_BASIS_TILES = 2;   // stage 1 computes 32 rows (the last LR_K - r of them are zero)
+constexpr uint32_t LR_MAX_CLASSES = 4;
+struct LowRank {
+    bool available = false;
+    uint32_t r = 0, n_cls = 0, frame_w = 0, frame_h = 0, n_live = 0;
+    int frame_class = -1;      // position (inside the super-class) of the class whose box is the frame, -1 if none
+    size_t basis_offset = 0;   // bytes into d_lr_basis
+    size_t g_offset = 0;       // bytes into d_lr_g (1 KiB per N-tile of the super-class)
+    float inv_lambda = 0.f;    // sum_j y_j^2 * inv_lambda <= |P (a - mean)|^2
+    double mean_rho = 0, max_rho = 0;
+};
+
 // Classes whose A fragments are identical (same K layout, same number of K-steps) are scanned in one kernel
 // pass: their N-tiles are concatenated; only the C-in table (negL) changes from class to class.
 struct SuperClass {
@@ -42,6 +56,7 @@ struct SuperClass {
     // per scan: window enumeration of the pass (smallest searchable template) and its live-tile list
     uint32_t min_w, min_h, mtx, n_rows;
     size_t live_offset;
+    LowRank lr;
 };
 
 // Per-template constants, computed once on the host in IEEE double exactly as
@@ -88,6 +103,12 @@ struct focr_ctx {
     uint32_t *d_direct_bank = nullptr;          // class-ordered, [maxh][ndw] dwords each
     std::vector<size_t> direct_bank_off;        // dword offset per class
     int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
+    int8_t *d_lr_basis = nullptr;               // two-stage prefilter: int8 basis rows (per-lane MFMA layout), all super-classes
+    uint16_t *d_lr_g = nullptr;                 // two-stage prefilter: bf16 stage-2 operand, 1 KiB per N-tile
+    bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
+    int prefilter = 0;                          // FOCR_PREFILTER_*: auto / single stage / two stages (focr_ctx_set_prefilter)
+    float *d_norms = nullptr;                   // two-stage path: window norms [super-class][page][Lrows][Lpitch][n_cls (+1)] f32
+    size_t norms_bytes = 0;
     uint32_t *d_tglobal = nullptr;              // class-ordered -> global template index, 0xffffffff = never emits
     uint32_t *d_order_of = nullptr;             // global template index -> class-ordered index
     std::vector<double> mfma_c_scale, mfma_e_max;  // per class: quantisation scale, max rounding-error norm
@@ -187,6 +208,10 @@ int launch_scan_mfma(focr_ctx *ctx, float threshold);
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
 int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
+void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
+                       std::vector<uint32_t> &direct, std::vector<uint8_t> &dense);
+void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layouts, bank offsets (host only)
+void build_lowrank(focr_ctx *c, SuperClass &su, const uint8_t *dense, std::vector<int8_t> &basis_bytes, std::vector<uint16_t> &g_bytes);
 
 // ---- device helpers: the reference's f64 epilogue, operation for operation ----
 // Compiled with -ffp-contract=off: the only fused operation is the explicit fma.

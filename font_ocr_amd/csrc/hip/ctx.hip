@@ -69,6 +69,8 @@ static void free_bank(focr_ctx *c) {
     free_dev(c->d_tconst);
     free_dev(c->d_direct_bank);
     free_dev(c->d_qbank);
+    free_dev(c->d_lr_basis);
+    free_dev(c->d_lr_g);
     free_dev(c->d_tglobal);
     free_dev(c->d_order_of);
     c->mfma_c_scale.clear();
@@ -104,6 +106,8 @@ static void free_results(focr_ctx *c) {
                     &c->acc_hkeys, &c->acc_hsims})
         b->release();
     free_dev(c->d_L);
+    free_dev(c->d_norms);
+    c->norms_bytes = 0;
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);
     free_dev(c->d_seg_start);
@@ -253,6 +257,18 @@ int focr_ctx_set_scan_cus(focr_ctx_t *c, unsigned max_cus) {
     return FOCR_OK;
 }
 
+int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
+    if (!c || mode < FOCR_PREFILTER_AUTO || mode > FOCR_PREFILTER_TWO_STAGE) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
+    c->prefilter = mode;
+    return FOCR_OK;
+}
+
+int focr_debug_force_split(focr_ctx_t *c, int on) {
+    if (!c) return FOCR_ERR_INVALID;
+    c->force_split = on != 0;
+    return FOCR_OK;
+}
+
 int focr_sync(focr_ctx_t *c) {
     if (!c) return FOCR_ERR_INVALID;
     FOCR_HIP(c, hipSetDevice(c->device));
@@ -277,6 +293,37 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
     free_bank(c);
     c->scanned = c->processed = false;
+    std::vector<uint32_t> direct;
+    std::vector<uint8_t> dense;
+    bank_host_prepare(c, templates, n_templates, needles, direct, dense);
+    std::vector<uint32_t> tw(n_templates), th(n_templates), tl(n_templates);
+    for (size_t t = 0; t < n_templates; t++) {
+        tw[t] = templates[t].n_w;
+        th[t] = templates[t].n_h;
+        tl[t] = templates[t].letter;
+    }
+    auto up = [&](auto *&dptr, const void *src, size_t bytes) -> int {
+        FOCR_HIP(c, hipMalloc((void **)&dptr, bytes ? bytes : 16));
+        FOCR_HIP(c, hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+        return FOCR_OK;
+    };
+    int rc;
+    if ((rc = up(c->d_tconst, c->h_tconst.data(), c->h_tconst.size() * sizeof(TemplateConst)))) return rc;
+    if ((rc = up(c->d_direct_bank, direct.data(), direct.size() * 4))) return rc;
+    if ((rc = up(c->d_needles, dense.data(), dense.size()))) return rc;
+    if ((rc = up(c->d_needle_off, c->h_needle_off.data(), c->h_needle_off.size() * 4))) return rc;
+    if ((rc = up(c->d_t_w, tw.data(), tw.size() * 4))) return rc;
+    if ((rc = up(c->d_t_h, th.data(), th.size() * 4))) return rc;
+    if ((rc = up(c->d_t_letter, tl.data(), tl.size() * 4))) return rc;
+    return build_mfma_bank(c, dense.data());
+}
+
+}  // extern "C"
+
+namespace focr {
+// Host-only part of the bank upload: size classes, class order, per-template constants, dense / direct-kernel needles.
+void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
+                       std::vector<uint32_t> &direct, std::vector<uint8_t> &dense) {
     c->n_templates = n_templates;
     c->h_templates.assign(templates, templates + n_templates);
 
@@ -309,8 +356,6 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
             return templates[a].shift_y < templates[b].shift_y;
         });
 
-    std::vector<uint32_t> direct;
-    std::vector<uint8_t> dense;
     uint32_t first = 0;
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
@@ -351,27 +396,10 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
             dense.insert(dense.end(), nd, nd + n);
         }
     }
-    std::vector<uint32_t> tw(n_templates), th(n_templates), tl(n_templates);
-    for (size_t t = 0; t < n_templates; t++) {
-        tw[t] = templates[t].n_w;
-        th[t] = templates[t].n_h;
-        tl[t] = templates[t].letter;
-    }
-    auto up = [&](auto *&dptr, const void *src, size_t bytes) -> int {
-        FOCR_HIP(c, hipMalloc((void **)&dptr, bytes ? bytes : 16));
-        FOCR_HIP(c, hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
-        return FOCR_OK;
-    };
-    int rc;
-    if ((rc = up(c->d_tconst, c->h_tconst.data(), c->h_tconst.size() * sizeof(TemplateConst)))) return rc;
-    if ((rc = up(c->d_direct_bank, direct.data(), direct.size() * 4))) return rc;
-    if ((rc = up(c->d_needles, dense.data(), dense.size()))) return rc;
-    if ((rc = up(c->d_needle_off, c->h_needle_off.data(), c->h_needle_off.size() * 4))) return rc;
-    if ((rc = up(c->d_t_w, tw.data(), tw.size() * 4))) return rc;
-    if ((rc = up(c->d_t_h, th.data(), th.size() * 4))) return rc;
-    if ((rc = up(c->d_t_letter, tl.data(), tl.size() * 4))) return rc;
-    return build_mfma_bank(c, dense.data());
 }
+}  // namespace focr
+
+extern "C" {
 
 int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
     if (!c || !n_pages || !r_w || !r_h) return fail(c, FOCR_ERR_INVALID, "focr_pages_alloc: bad arguments");
@@ -576,9 +604,8 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         if (r) return r;
         return c->ordered ? FOCR_OK : order_hits(c);
     };
-    // FOCR_FORCE_SPLIT=1 (tests): take the split-batch path without waiting for an overflow
-    const bool force_split = getenv("FOCR_FORCE_SPLIT") && atoi(getenv("FOCR_FORCE_SPLIT")) != 0;
-    int rc = force_split ? FOCR_ERR_OVERFLOW : run(0, c->n_pages);
+    // focr_debug_force_split (tests): take the split-batch path without waiting for an overflow
+    int rc = c->force_split ? FOCR_ERR_OVERFLOW : run(0, c->n_pages);
     if (rc == FOCR_ERR_OVERFLOW || rc == FOCR_ERR_NOMEM) {
         // Too many candidates for one pass (very low thresholds): scan the batch in page sub-ranges and append the
         // results.  Only hits that survive the per-call cap are kept, so the totals stay bounded by pages x T x cap.

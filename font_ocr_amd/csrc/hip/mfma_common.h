@@ -79,6 +79,53 @@ struct MfmaLaunch {
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)
 };
 
+// ---- two-stage prefilter (scan_mfma3.hip; host data: lowrank.hip) ----
+// Window norms of one super-class, planar: norms[v][page][Lrows][Lpitch] f32, value v = sqrt(V / n) of box v
+// (V = n*s2 - s^2, exact integer).  Values 0 .. n_cls-1 are the super-class's size classes and carry the class's emit
+// flag in the sign (> 0: the reference can emit there: x, y >= 1, window inside the page, variance > 0; <= 0: never);
+// when no class has the frame's box, one more value holds the frame norm.  |value| is always the norm.
+constexpr int LR_MAX_VALUES = 4;
+struct StatsLR {
+    uint32_t nwid, nv, n_cls, maxh;
+    uint32_t wid[4];                 // distinct box widths
+    uint32_t v_wid[LR_MAX_VALUES];   // per value: index into wid[]
+    uint32_t v_w[LR_MAX_VALUES], v_h[LR_MAX_VALUES], v_n[LR_MAX_VALUES];
+    float v_rn[LR_MAX_VALUES];       // 1 / n
+};
+
+// Stage-2 K slots (LR_K = 32): slot = 16 b + 4 g + v lives in lane group g, element 4 b + v of the 8-element bf16
+// operand.  The 2 + n_cls "extras" (R, N_F, one threshold slot per class) sit at compile-time element positions so the
+// kernel places them with a select on the lane group only: extra e < 4 -> element 7 of lane group e, extra e >= 4 ->
+// element 6 of lane group e - 4.  The r principal directions fill the remaining slots in increasing slot order.
+__host__ __device__ inline uint32_t lr_extra_slot(uint32_t e) { return e < 4 ? 16 + 4 * e + 3 : 16 + 4 * (e - 4) + 2; }
+inline uint32_t lr_comp_slot(uint32_t j, uint32_t n_extras) {  // host: slot of principal direction j
+    for (uint32_t s = 0, k = 0; s < LR_K; s++) {
+        bool is_extra = false;
+        for (uint32_t e = 0; e < n_extras; e++) is_extra |= lr_extra_slot(e) == s;
+        if (is_extra) continue;
+        if (k == j) return s;
+        k++;
+    }
+    return 0xffffffffu;
+}
+
+struct Mfma3Args {
+    const float *norms;      // value 0 of the sub-batch's first page; values are `norm_stride` floats apart
+    size_t norm_stride;      // floats between consecutive values
+    uint32_t nv, n_cls, frame_value;  // frame_value: index of the value that holds the frame norm
+    float inv_lambda;
+    float thr_lo;            // thr_eff widened by 2^-20 away from the emitting side: theta = thr_lo * norm_c is a lower bound
+    uint32_t theta_add;      // 0xffff if thr_lo < 0 (bf16 rounding of theta towards -inf), else 0
+    float kq[MAX_SEGS];      // per segment of the launch: L = floor(kq * norm_c) - 2, the exact-taps stage's threshold
+    uint32_t seg_value[MAX_SEGS];  // per segment: the norm value of its class
+};
+
+// scan_mfma3.hip
+uint32_t mfma3_chunk_tiles(uint32_t ksteps);
+int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus);
+int launch_stats_lr(focr_ctx *c, const SuperClass &su, const StatsLR &P, float *norms, size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
+                    uint8_t *live, uint32_t mtx, uint32_t n_rows);
+
 // scan_mfma2.hip
 size_t mfma2_bank_budget();
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
 // host side
 
 // Quantise the bank (see the header comment).  `dense` holds the class-ordered dense needles.
-int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
+void layout_supers(focr_ctx *c) {
     // K layout per class (mfma_common.h).  Narrow classes ride the 12-byte-row layout whenever a 9..12-wide
     // class exists, so that all of them share one set of A fragments (one "super-class", one kernel pass).
     bool any_mid = false;
@@ -288,6 +288,15 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
             sc.q_offset = (uint32_t)(su.q_offset + (size_t)su.tile_first[i] * su.ksteps * 1024);
             sc.tg_offset = (uint32_t)(su.tg_offset + (size_t)su.tile_first[i] * 16);
         }
+    }
+}
+
+int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
+    layout_supers(c);
+    size_t q_bytes = 0, tg_entries = 0;
+    for (const SuperClass &su : c->supers) {
+        q_bytes += (size_t)su.n_tiles * su.ksteps * 1024;
+        tg_entries += (size_t)su.n_tiles * 16;
     }
     std::vector<int8_t> qbank(q_bytes, 0);
     std::vector<uint32_t> tglobal(tg_entries, 0xffffffffu), order_of(c->n_templates, 0);
@@ -366,6 +375,15 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     }
     FOCR_HIP(c, hipMalloc((void **)&c->d_qbank, qbank.size() ? qbank.size() : 16));
     FOCR_HIP(c, hipMemcpy(c->d_qbank, qbank.data(), qbank.size(), hipMemcpyHostToDevice));
+    {  // two-stage prefilter data (lowrank.hip), per super-class that qualifies
+        std::vector<int8_t> basis;
+        std::vector<uint16_t> gb;
+        for (SuperClass &su : c->supers) build_lowrank(c, su, dense, basis, gb);
+        FOCR_HIP(c, hipMalloc((void **)&c->d_lr_basis, basis.size() ? basis.size() : 16));
+        FOCR_HIP(c, hipMemcpy(c->d_lr_basis, basis.data(), basis.size(), hipMemcpyHostToDevice));
+        FOCR_HIP(c, hipMalloc((void **)&c->d_lr_g, gb.size() ? gb.size() * 2 : 16));
+        FOCR_HIP(c, hipMemcpy(c->d_lr_g, gb.data(), gb.size() * 2, hipMemcpyHostToDevice));
+    }
     FOCR_HIP(c, hipMalloc((void **)&c->d_tglobal, tglobal.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_tglobal, tglobal.data(), tglobal.size() * 4, hipMemcpyHostToDevice));
     // verify operand: every template as n_h rows of 16 bytes (zero padded), class-ordered
@@ -448,8 +466,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
-        uint32_t dbg = 0;
-        if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
         size_t tiles_total = 0;
         for (SuperClass &su : c->supers) {
             su.min_w = su.min_h = 0xffffffffu;
@@ -472,28 +488,76 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
         if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
         FOCR_HIP(c, hipMemsetAsync(live, 0, tiles_total + 16, c->stream));
+        // which super-classes take the two-stage prefilter (scan_mfma3.hip), and their window-norm planes
+        const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // floats per norm value
+        std::vector<int> two(c->supers.size(), 0);
+        std::vector<size_t> norm_off(c->supers.size(), 0);
+        std::vector<uint32_t> norm_nv(c->supers.size(), 0);
+        size_t norm_floats = 0;
+        for (size_t si = 0; si < c->supers.size(); si++) {
+            const SuperClass &su = c->supers[si];
+            if (!su.mtx || !su.lr.available || c->prefilter == FOCR_PREFILTER_ONE_STAGE) continue;
+            const uint32_t nv = su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0);
+            if (nv > (uint32_t)LR_MAX_VALUES) continue;
+            // AUTO: worth it when the bank compresses (mean residual of the unit templates) and there are enough N-tiles
+            // for the saved taps to outweigh the 2 basis tiles + the bf16 pass
+            if (c->prefilter == FOCR_PREFILTER_AUTO && !(su.lr.mean_rho < 0.45 && su.n_tiles >= 8)) continue;
+            two[si] = 1;
+            norm_nv[si] = nv;
+            norm_off[si] = norm_floats;
+            norm_floats += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernel is instantiated for 1 / 2 / 4 values
+        }
+        if (c->norms_bytes < norm_floats * 4) {
+            FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_norms) (void)hipFree(c->d_norms);
+            c->d_norms = nullptr;
+            c->norms_bytes = 0;
+            if (hipMalloc((void **)&c->d_norms, norm_floats * 4) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(norms) failed");
+            c->norms_bytes = norm_floats * 4;
+        }
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            for (uint32_t k : su.classes) {
-                const SizeClass &sc = c->classes[k];
-                if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
-                const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
-                const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
-                int32_t *negL = c->d_L + k * L_per_class;
-                uint8_t *lv = live + su.live_offset;
-                switch (sc.ndw) {
-                    case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                    case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                    case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                    case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                    default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+            if (two[si]) {  // one fused pass: the norms of every class box and of the frame
+                StatsLR P{};
+                P.n_cls = su.lr.n_cls;
+                P.nv = norm_nv[si];
+                for (uint32_t v = 0; v < P.nv; v++) {
+                    const uint32_t bw = v < P.n_cls ? c->classes[su.classes[v]].n_w : su.lr.frame_w;
+                    const uint32_t bh = v < P.n_cls ? c->classes[su.classes[v]].n_h : su.lr.frame_h;
+                    uint32_t wi = 0;
+                    for (; wi < P.nwid; wi++)
+                        if (P.wid[wi] == bw) break;
+                    if (wi == P.nwid) P.wid[P.nwid++] = bw;
+                    P.v_wid[v] = wi;
+                    P.v_w[v] = bw;
+                    P.v_h[v] = bh;
+                    P.v_n[v] = bw * bh;
+                    P.v_rn[v] = 1.0f / (float)(bw * bh);
+                    P.maxh = std::max(P.maxh, bh);
                 }
-                FOCR_HIP(c, hipGetLastError());
+                if ((rc = launch_stats_lr(c, su, P, c->d_norms + norm_off[si], plane, Lpitch, Lrows, live + su.live_offset, su.mtx, su.n_rows))) return rc;
+            } else {
+                for (uint32_t k : su.classes) {
+                    const SizeClass &sc = c->classes[k];
+                    if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
+                    const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
+                    const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
+                    int32_t *negL = c->d_L + k * L_per_class;
+                    uint8_t *lv = live + su.live_offset;
+                    switch (sc.ndw) {
+                        case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                        case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                        case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                        case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
+                        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+                    }
+                    FOCR_HIP(c, hipGetLastError());
+                }
             }
             const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->sub_np);
             hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
-                               su.n_rows, (dbg & 8) ? 0u : 1u, live_list + su.live_offset, c->d_counter + 8 + si);
+                               su.n_rows, 1u, live_list + su.live_offset, c->d_counter + 8 + si);
             FOCR_HIP(c, hipGetLastError());
         }
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
@@ -510,12 +574,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             for (hipEvent_t &e : tn.ev) FOCR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             tn.init = true;
         }
-        static const bool no_turns = getenv("FOCR_NO_SCAN_TURNS") != nullptr;  // A/B experiments only
-        if (tn.n && !no_turns) FOCR_HIP(c, hipStreamWaitEvent(c->stream, tn.ev[(tn.n - 1) % 8], 0));
+        if (tn.n) FOCR_HIP(c, hipStreamWaitEvent(c->stream, tn.ev[(tn.n - 1) % 8], 0));
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            const uint32_t chunk_tiles = (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
+            const uint32_t chunk_tiles = two[si] ? mfma3_chunk_tiles(su.ksteps) : (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
             uint32_t t0 = 0;
             while (t0 < su.n_tiles) {
                 MfmaLaunch L{};
@@ -530,24 +593,35 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.super_index = (uint32_t)si;
                 const uint32_t t_limit = std::min(su.n_tiles, t0 + chunk_tiles);
                 uint32_t t1 = t0;
+                Mfma3Args A3{};
                 for (size_t i = 0; i < su.classes.size() && L.segs.n < (uint32_t)MAX_SEGS; i++) {
                     const SizeClass &sc = c->classes[su.classes[i]];
                     const uint32_t cb = su.tile_first[i], ce = cb + sc.n_tiles16;
                     const uint32_t b = std::max(cb, t1), e = std::min(ce, t_limit);
                     if (b >= e || b != t1) continue;  // segments must tile [t0, t1) contiguously
-                    if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) {  // no searchable window: skip the class's tiles
+                    if (!two[si] && (sc.n_w >= c->r_w || sc.n_h >= c->r_h)) {  // no searchable window: skip the class's tiles
                         if (L.segs.n == 0) {
                             t0 = t1 = e;
                             continue;
                         }
                         break;
                     }
+                    {  // the exact-taps stage's threshold scale of the segment's class (two-stage kernel: L = floor(kq * norm) - 2)
+                        const double cs = c->mfma_c_scale[su.classes[i]], em = c->mfma_e_max[su.classes[i]];
+                        const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
+                        float kq = (float)kappa;
+                        if ((double)kq > kappa) kq = std::nextafterf(kq, -INFINITY);
+                        kq = std::nextafterf(kq, -INFINITY);
+                        A3.kq[L.segs.n] = std::isfinite(kq) ? kq : -3.0e38f;
+                        A3.seg_value[L.segs.n] = (uint32_t)i;
+                    }
                     MfmaSeg &sg = L.segs.s[L.segs.n++];
                     sg.negL = c->d_L + su.classes[i] * L_per_class;
                     sg.tile_end = e - t0;
                     const uint32_t real = std::min(sc.n_templates, (e - cb) * 16) - (b - cb) * 16;
                     L.n_templates += real;
-                    L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->sub_np;
+                    if (sc.n_w < c->r_w && sc.n_h < c->r_h)
+                        L.alg_macs += (uint64_t)(c->r_w - sc.n_w) * (c->r_h - sc.n_h) * sc.n_w * sc.n_h * real * c->sub_np;
                     t1 = e;
                 }
                 if (L.segs.n == 0) {
@@ -558,7 +632,25 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
                 const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
-                if ((rc = dispatch_mfma_v2(c, L, cus))) return rc;
+                if (two[si]) {
+                    A3.norms = c->d_norms + norm_off[si];
+                    A3.norm_stride = plane;
+                    A3.nv = norm_nv[si];
+                    A3.n_cls = su.lr.n_cls;
+                    A3.frame_value = su.lr.frame_class >= 0 ? (uint32_t)su.lr.frame_class : su.lr.n_cls;
+                    A3.inv_lambda = su.lr.inv_lambda;
+                    // the reference emits iff sim > thr; thr_eff leaves 1e-4 for the f64 roundings of its formula, thr_lo
+                    // another 2^-20 for the f32 norm on the device.  Similarities live in [-1, 1]: below -2 nothing changes.
+                    const double te = std::max(thr_d - 1e-4 * (1.0 + std::fabs(thr_d)), -2.0);
+                    const double tl = te >= 0 ? te * (1.0 - std::ldexp(1.0, -20)) : te * (1.0 + std::ldexp(1.0, -20));
+                    A3.thr_lo = (float)tl;
+                    if ((double)A3.thr_lo > tl) A3.thr_lo = std::nextafterf(A3.thr_lo, -INFINITY);
+                    A3.theta_add = A3.thr_lo < 0.f ? 0xffffu : 0u;
+                    if ((rc = dispatch_mfma_v3(c, L, A3, c->d_lr_basis + su.lr.basis_offset, (const uint16_t *)((const uint8_t *)c->d_lr_g + su.lr.g_offset) + (size_t)t0 * 512, cus)))
+                        return rc;
+                } else if ((rc = dispatch_mfma_v2(c, L, cus))) {
+                    return rc;
+                }
                 t0 = t1;
             }
         }
@@ -581,7 +673,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipStreamSynchronize(c->stream));
         c->counters[3] = 0;
         for (focr_launch_info_t &li : c->launches) {  // issued MACs follow the number of live M-tiles (known only now)
-            if (strncmp(li.name, "scan_mfma2", 10) == 0) {
+            if (strncmp(li.name, "scan_mfma", 9) == 0) {
                 li.issued_macs *= live_counts[li.n_templates >> 24];
                 li.n_templates &= 0xffffff;
             }

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t dbg) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -79,10 +79,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
         }
         // A fragments: lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r.
         // Byte-unaligned 16-byte (8-byte) global loads land directly in the MFMA operand registers.
-        if (!(dbg & 2) || item == xc * per_xc + slot * NW + w)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + ((dbg & 4) ? 0 : r);
+            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ks++) {
                 v4i a;
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                 m = max(max(m, acc[mt][0]), acc[mt][1]);
                 m = max(max(m, acc[mt][2]), acc[mt][3]);
             }
-            if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
+            if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
@@ -205,15 +204,13 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const v4i *qb = reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset);
     const uint64_t issued = 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;  // per live M-tile; scaled by the live count after the scan
-    uint32_t dbg = 0;  // FOCR_MFMA_DBG: timing experiments only (bit0: skip candidate emission, bit1: reuse first A fragments)
-    if (const char *e = getenv("FOCR_MFMA_DBG")) dbg = (uint32_t)atoi(e);
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
-                       (unsigned long long)c->cand_capacity, dbg);
+                       (unsigned long long)c->cand_capacity);
     c->launch_end();
 }
 

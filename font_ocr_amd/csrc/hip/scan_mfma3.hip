@@ -1,0 +1,433 @@
+// scan_mfma3.hip — two-stage MFMA prefilter (the maths and the host data: lowrank.hip).
+//
+// Same worker structure as scan_mfma2.hip (every wave an independent worker over MT 16-window M-tiles of the live-tile
+// list, A fragments straight from HBM/L2, one barrier after staging the bank), but per item:
+//
+//   stage 1   y = U^ (a - 128): the int8 basis (2 N-tiles = 32 rows, the unused ones zero) against the window fragments.
+//             Operand roles are (A = basis, B = windows), so lane (r, g) ends up with rows 4g..4g+3 of both basis tiles
+//             for ITS OWN window px + r — exactly the 8 K-slots {16 b + 4 g + v} that lane group g feeds to stage 2:
+//             no lane movement between the stages.
+//   mid       y -> bf16; sum of squares over the lane groups (2 shuffles) -> R(w); R, N_F and the per-class threshold
+//             slots theta_c = thr_lo * norm_c(w) go into their compile-time element positions (mfma_common.h).
+//   stage 2   one v_mfma_f32_16x16x32_bf16 per (M-tile, N-tile): D2[template][window]; any D2 > 0 sets bit nt of the
+//             M-tile's mask.  No branch, no candidate handling in this loop.
+//   stage 3   for the set bits only: the exact-taps int8 stage of scan_mfma2.hip on that (M-tile, N-tile) block, again as
+//             (A = templates, B = windows), so the C-in of lane (r, g) is the threshold of its own window for all four
+//             registers: -(floor(kq * norm_c) - 2), from the norm the lane already holds.  Survivors are candidates.
+//
+// Window norms come from stats_lr_kernel below (one fused pass per super-class: all size classes + the frame).
+#include <algorithm>
+
+#include "mfma_common.h"
+
+namespace focr {
+
+typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned views: gfx950 global loads take any alignment
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef v2i v2i_u __attribute__((aligned(1)));
+typedef int v3i __attribute__((ext_vector_type(3)));
+typedef v3i v3i_u __attribute__((aligned(1)));
+typedef int int_u __attribute__((aligned(1)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------
+// window norms of a super-class: separable sliding sums as in scan_mfma.hip's stats_kernel, all boxes in one pass
+constexpr int STX = 64, STY = 32, SLDW = 21;
+static inline size_t stats_lr_lds_bytes(const StatsLR &P) {
+    const size_t rows = STY + P.maxh - 1;
+    return rows * (SLDW * 4 + (size_t)P.nwid * STX * 6);
+}
+
+template <bool SMALLN>
+__global__ __launch_bounds__(256) void stats_lr_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
+                                                       uint32_t r_w, uint32_t r_h, const StatsLR P, float *__restrict__ norms,
+                                                       size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
+                                                       uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
+    extern __shared__ uint32_t slr_lds[];
+    const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
+    const uint32_t rows = STY + P.maxh - 1;
+    uint32_t (*tile)[SLDW] = reinterpret_cast<uint32_t (*)[SLDW]>(slr_lds);
+    uint32_t *H2 = slr_lds + rows * SLDW;                                                // [wid][row][STX] u32
+    uint16_t *H = reinterpret_cast<uint16_t *>(slr_lds + rows * SLDW + P.nwid * rows * STX);  // [wid][row][STX] u16 (<= 16 * 255)
+    const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
+    for (uint32_t i = threadIdx.x; i < rows * SLDW; i += 256) {
+        uint32_t r = i / SLDW, cdw = i % SLDW;
+        uint32_t gy = y0 + r, gx = x0 + cdw * 4;
+        uint32_t v = 0;
+        if (gy < rows_alloc && gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t *>(pg + (size_t)gy * pitch + gx);
+        tile[r][cdw] = v;
+    }
+    __syncthreads();
+    {  // horizontal sums of every distinct width
+        const uint32_t lane = threadIdx.x & 63, cb = lane >> 2, sh = lane & 3;
+        for (uint32_t r = threadIdx.x >> 6; r < rows; r += 4) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w4[k] = __builtin_amdgcn_alignbyte(tile[r][cb + k + 1], tile[r][cb + k], sh);
+            for (uint32_t wi = 0; wi < P.nwid; wi++) {
+                const uint32_t n_w = P.wid[wi];
+                uint32_t h = 0, h2 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
+                    const uint32_t w = w4[k] & keep;
+                    h = __builtin_amdgcn_udot4(w, 0x01010101u, h, false);
+                    h2 = __builtin_amdgcn_udot4(w, w, h2, false);
+                }
+                H[(wi * rows + r) * STX + lane] = (uint16_t)h;
+                H2[(wi * rows + r) * STX + lane] = h2;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t col = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const uint32_t x = x0 + col;
+    if (x >= Lpitch) return;
+    constexpr uint32_t PER = STY / 4;
+    const uint32_t r0 = strip * PER;
+    uint32_t s[LR_MAX_VALUES], s2[LR_MAX_VALUES];
+#pragma unroll
+    for (int v = 0; v < LR_MAX_VALUES; v++) {
+        s[v] = s2[v] = 0;
+        if ((uint32_t)v < P.nv) {
+            const uint32_t base = P.v_wid[v] * rows;
+            for (uint32_t j = 0; j < P.v_h[v]; j++) {
+                s[v] += H[(base + r0 + j) * STX + col];
+                s2[v] += H2[(base + r0 + j) * STX + col];
+            }
+        }
+    }
+    const uint32_t ya = y0 + r0;
+    const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
+    const size_t live_i = ((size_t)page * n_rows + ya) * mtx + (x >> 4);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t y = ya + k;
+        if (y < Lrows) {
+            bool any_emit = false;
+#pragma unroll
+            for (int v = 0; v < LR_MAX_VALUES; v++) {
+                if ((uint32_t)v < P.nv) {
+                    // V = n*s2 - s*s, exact; V > 0 <=> the reference's rnorm is finite (src/ncc.rs:309-311)
+                    float Vf;
+                    if (SMALLN) Vf = (float)(P.v_n[v] * s2[v] - s[v] * s[v]);
+                    else Vf = (float)((uint64_t)P.v_n[v] * s2[v] - (uint64_t)s[v] * s[v]);
+                    // norm = sqrt(V / n): relative error < 4 * 2^-24 (conversion, product with the rounded 1/n, 1-ulp sqrt)
+                    float nrm = __builtin_amdgcn_sqrtf(Vf * P.v_rn[v]);
+                    if ((uint32_t)v < P.n_cls) {
+                        // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
+                        const bool emit = x >= 1 && x + P.v_w[v] <= r_w && y >= 1 && y + P.v_h[v] <= r_h && Vf > 0.f;
+                        any_emit |= emit;
+                        if (!emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
+                    }
+                    norms[(size_t)v * norm_stride + ((size_t)page * Lrows + y) * Lpitch + x] = nrm;
+                    if (k + 1 < PER) {  // slide down one row
+                        const uint32_t base = P.v_wid[v] * rows;
+                        s[v] += H[(base + r0 + k + P.v_h[v]) * STX + col] - H[(base + r0 + k) * STX + col];
+                        s2[v] += H2[(base + r0 + k + P.v_h[v]) * STX + col] - H2[(base + r0 + k) * STX + col];
+                    }
+                }
+            }
+            const uint64_t lm = __builtin_amdgcn_ballot_w64(any_emit);
+            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
+        }
+    }
+}
+
+int launch_stats_lr(focr_ctx *c, const SuperClass &su, const StatsLR &P, float *norms, size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
+                    uint8_t *live, uint32_t mtx, uint32_t n_rows) {
+    (void)su;
+    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
+    bool small = true;
+    for (uint32_t v = 0; v < P.nv; v++) small &= P.v_n[v] <= 256;
+    const size_t lds = stats_lr_lds_bytes(P);
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, P, norms, norm_stride, Lpitch, Lrows, live, mtx, n_rows);
+    };
+    if (small) launch(stats_lr_kernel<true>);
+    else launch(stats_lr_kernel<false>);
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr size_t V3_LDS_TOTAL = 160 << 10;
+
+// N-tiles of one launch: i8 templates (ksteps KiB) + bf16 stage-2 operand (1 KiB) + template ids (64 B) per tile, next to
+// the basis, the candidate staging buffers and a little slack; the per-M-tile masks have 64 bits
+uint32_t mfma3_chunk_tiles(uint32_t ksteps) {
+    const size_t fixed = (size_t)LR_BASIS_TILES * ksteps * 1024 + (size_t)16 * WBUF * 8 + 1024;
+    return (uint32_t)std::min<size_t>(64, (V3_LDS_TOTAL - fixed) / ((size_t)ksteps * 1024 + 1024 + 64));
+}
+
+__device__ __forceinline__ uint32_t pack_bf16_bits(uint32_t hi_f32_bits, uint32_t lo_f32_bits) {
+    return __builtin_amdgcn_perm(hi_f32_bits, lo_f32_bits, 0x07060302u);  // {hi[31:16], lo[31:16]}
+}
+
+template <int KSTEPS, int RPG, int MT, int NW, int NV>
+__global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
+    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
+    const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, const v4i *__restrict__ basis_g,
+    const v4i *__restrict__ gbank_g, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows, const Mfma3Args P,
+    const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem3[];
+    v4i *bank = reinterpret_cast<v4i *>(smem3);
+    const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
+    v4i *basis = bank + bank_vec;
+    constexpr uint32_t basis_vec = LR_BASIS_TILES * KSTEPS * 64;
+    v4i *gb = basis + basis_vec;
+    const uint32_t gb_vec = n_tiles16 * 64;
+    uint64_t *wbuf_all = reinterpret_cast<uint64_t *>(gb + gb_vec);
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(wbuf_all + (size_t)NW * WBUF);
+    for (uint32_t i = threadIdx.x; i < bank_vec; i += NW * 64) bank[i] = qbank[i];
+    for (uint32_t i = threadIdx.x; i < basis_vec; i += NW * 64) basis[i] = basis_g[i];
+    for (uint32_t i = threadIdx.x; i < gb_vec; i += NW * 64) gb[i] = gbank_g[i];
+    for (uint32_t i = threadIdx.x; i < n_tiles16 * 16; i += NW * 64) tg_lds[i] = tglobal[i];
+    __syncthreads();  // the only barrier
+
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint64_t *wbuf = wbuf_all + w * WBUF;
+    uint32_t wcount = 0;
+
+    const uint32_t total_mt = *live_count;
+    const uint32_t n_items = (total_mt + MT - 1) / MT;
+    const uint32_t n_xc = min(8u, gridDim.x);
+    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
+    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;
+    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
+    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
+    const uint32_t stride = xc_blocks * NW;
+    const uint32_t n_extras = 2 + P.n_cls;
+
+    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
+        const uint32_t m0 = item * MT;
+        uint32_t px[MT], py[MT], pp[MT];
+        bool pv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            pv[mt] = m0 + mt < total_mt;
+            const uint64_t e = live_list[pv[mt] ? m0 + mt : total_mt - 1];
+            px[mt] = 16 * (uint32_t)(e & 0xfff);
+            py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);
+            pp[mt] = (uint32_t)(e >> 32);
+        }
+        // norms of the lane's own window px + r (all four lane groups read the same values)
+        float nrm[MT][NV];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const float *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+#pragma unroll
+            for (int v = 0; v < NV; v++) nrm[mt][v] = np[(size_t)v * P.norm_stride];
+        }
+        // A fragments (as scan_mfma2.hip): lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r
+        v4i afrag[MT][KSTEPS];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                v4i a;
+                if (RPG == LAYOUT_W16) {
+                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)(4 * ks + g) * pitch);
+                } else if (RPG == LAYOUT_W8) {
+                    const uint8_t *p0 = base + (size_t)(2 * (4 * ks + g)) * pitch;
+                    const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
+                    a = v4i{lo[0], lo[1], hi[0], hi[1]};
+                } else {
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
+                    if (ks % 3 == 0) {
+                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
+                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
+                        a = v4i{t[0], t[1], t[2], u};
+                    } else if (ks % 3 == 1) {
+                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
+                        a = v4i{t[0], t[1], u[0], u[1]};
+                    } else {
+                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
+                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
+                        a = v4i{t, u[0], u[1], u[2]};
+                    }
+                }
+                afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): every int8 operand row sums to zero
+            }
+        }
+        // ---- stage 1: y = basis x windows^T ----
+        v4i y[MT][LR_BASIS_TILES];
+#pragma unroll
+        for (int b = 0; b < (int)LR_BASIS_TILES; b++) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) y[mt][b] = v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                const v4i uf = basis[(b * KSTEPS + ks) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) y[mt][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(uf, afrag[mt][ks], y[mt][b], 0, 0, 0);
+            }
+        }
+        // ---- mid: bf16 operand of stage 2 ----
+        v4i zf[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            float f[8];
+            float ss = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    f[4 * b + v] = (float)y[mt][b][v];  // |y| < 2^23: exact
+                    ss = __builtin_fmaf(f[4 * b + v], f[4 * b + v], ss);  // the extras' basis rows are zero: no masking needed
+                }
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            float nF = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; v++) nF = ((uint32_t)v == P.frame_value) ? __builtin_fabsf(nrm[mt][v]) : nF;
+            // R >= sqrt(N_F^2 - |P(a - mean)|^2): N_F^2 widened by 2^-20 (the norm carries < 4 * 2^-24 of error), the
+            // subtrahend already narrowed by inv_lambda's margin; sqrt 1 ulp + its own product: another 2^-20
+            const float nF2 = nF * nF * (1.f + 0x1p-20f);
+            float R = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-ss, P.inv_lambda, nF2), 0.f)) * (1.f + 0x1p-20f);
+            // extras as f32 bit patterns already rounded in the safe direction at bit 16 (bf16 = the high half):
+            //   R, N_F up; theta_c = thr_lo * norm_c towards -inf; classes that cannot emit here get an unreachable threshold
+            uint32_t X[4 + 4];
+            X[0] = __float_as_uint(R) + 0xffffu;
+            X[1] = __float_as_uint(nF * (1.f + 0x1p-20f)) + 0xffffu;
+#pragma unroll
+            for (int ci = 0; ci < (int)LR_MAX_CLASSES; ci++) {
+                float th = 3.0e38f;
+                uint32_t add = 0;
+                if (ci < NV && (uint32_t)ci < P.n_cls) {
+                    const float nc = nrm[mt][ci < NV ? ci : 0];
+                    if (nc > 0.f) {
+                        th = P.thr_lo * nc;
+                        add = P.theta_add;
+                    }
+                }
+                X[2 + ci] = __float_as_uint(th) + add;
+            }
+            X[6] = X[7] = 0;
+            // element 7 <- extra g (g < n_extras), element 6 <- extra 4 + g (4 + g < n_extras)
+            const uint32_t x7 = g == 0 ? X[0] : g == 1 ? X[1] : g == 2 ? X[2] : X[3];
+            const uint32_t x6 = g == 0 ? X[4] : g == 1 ? X[5] : 0u;
+            const bool e7 = (uint32_t)g < n_extras, e6 = (uint32_t)(4 + g) < n_extras;
+            const v2bf p01 = v2bf{(__bf16)f[0], (__bf16)f[1]}, p23 = v2bf{(__bf16)f[2], (__bf16)f[3]}, p45 = v2bf{(__bf16)f[4], (__bf16)f[5]};
+            const v2bf p67 = v2bf{(__bf16)f[6], (__bf16)f[7]};
+            const uint32_t u67 = __builtin_bit_cast(uint32_t, p67);
+            const uint32_t lo6 = e6 ? (x6 >> 16) : (u67 & 0xffffu), hi7 = e7 ? (x7 & 0xffff0000u) : (u67 & 0xffff0000u);
+            zf[mt] = v4i{(int)__builtin_bit_cast(uint32_t, p01), (int)__builtin_bit_cast(uint32_t, p23), (int)__builtin_bit_cast(uint32_t, p45),
+                         (int)(hi7 | lo6)};
+        }
+        // ---- stage 2: D2[template][window] per (M-tile, N-tile); set bit nt of the M-tile's mask if any D2 > 0 ----
+        uint64_t mask[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) mask[mt] = 0;
+        for (uint32_t nt = 0; nt < n_tiles16; nt++) {
+            const v8bf gq = __builtin_bit_cast(v8bf, gb[nt * 64 + lane]);
+            v4f d[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                d[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq, __builtin_bit_cast(v8bf, zf[mt]), v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const float m = __builtin_fmaxf(__builtin_fmaxf(d[mt][0], d[mt][1]), __builtin_fmaxf(d[mt][2], d[mt][3]));
+                const uint64_t any = __builtin_amdgcn_ballot_w64(m > 0.f);
+                mask[mt] |= (uint64_t)(any != 0) << nt;
+            }
+        }
+        // ---- stage 3: exact-taps int8 check of the flagged (M-tile, N-tile) blocks ----
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            uint64_t m = pv[mt] ? mask[mt] : 0;  // M-tiles past the end of the enumeration never flag
+            while (m) {
+                const uint32_t nt = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t sgi = 0;
+                while (sgi + 1 < segs.n && nt >= segs.s[sgi].tile_end) sgi++;  // the block's size class
+                float nc = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; v++) nc = ((uint32_t)v == P.seg_value[sgi]) ? nrm[mt][v] : nc;
+                // C-in = -(floor(kq * norm_c) - 2) of the lane's own window (scan_mfma.hip: conservative for |L| < 4e6), or
+                // -REJECT where the class never emits
+                float Lf = __builtin_floorf(P.kq[sgi] * nc) - 2.0f;
+                Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+                const int cin = nc > 0.f ? -(int)Lf : -REJECT;
+                v4i acc = v4i{cin, cin, cin, cin};
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++)
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bank[(nt * KSTEPS + ks) * 64 + lane], afrag[mt][ks], acc, 0, 0, 0);
+                const int mm = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+                if (__builtin_amdgcn_ballot_w64(mm > 0) == 0) continue;  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool f = acc[i] > 0;
+                    const uint64_t fm = __builtin_amdgcn_ballot_w64(f);
+                    if (!fm) continue;  // wave-uniform
+                    // lane (r, g), register i: template 4g + i of the tile, window px + r
+                    const uint32_t tg = f ? tg_lds[nt * 16 + 4 * g + i] : 0xffffffffu;
+                    const bool ok = tg != 0xffffffffu;  // dead / padding templates never emit
+                    const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
+                    if (!cnt) continue;
+                    if (wcount + cnt > WBUF) {
+                        flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                        wcount = 0;
+                    }
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
+                    if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pp[mt], py[mt], px[mt] + r, tg);
+                    wcount += cnt;
+                }
+            }
+        }
+    }
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+}
+
+template <int KSTEPS, int RPG, int NV>
+static void launch_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus) {
+    constexpr int MT = 4, NW = 16;
+    const uint32_t n_tiles16 = L.n_tiles16;
+    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)LR_BASIS_TILES * KSTEPS * 1024 + (size_t)n_tiles16 * 1024 + (size_t)NW * WBUF * 8 +
+                       (size_t)n_tiles16 * 16 * 4;
+    const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;
+    const uint64_t n_items = (total_mt + MT - 1) / MT;
+    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
+    auto kern = scan_mfma3_kernel<KSTEPS, RPG, MT, NW, NV>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // MACs issued per live M-tile: stage 1 (2 tiles of int8 K = 64 K-steps) + stage 2 (bf16 K = 32 per N-tile); the exact-taps
+    // stage's share depends on the data and is not counted here
+    const uint64_t issued = 16 * ((uint64_t)LR_BASIS_TILES * 16 * KSTEPS * 64 + (uint64_t)n_tiles16 * 16 * 32);
+    char name[64];
+    snprintf(name, sizeof name, "scan_mfma3_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
+    c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                       (uint32_t)c->rows_alloc, L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset),
+                       reinterpret_cast<const v4i *>(basis), reinterpret_cast<const v4i *>(gbank), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
+    c->launch_end();
+}
+
+int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus) {
+    const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);
+#define CASE3(K, R)                                                              \
+    case (K) * 10 + (R):                                                         \
+        if (nvp == 1) launch_v3<K, R, 1>(c, L, A3, basis, gbank, n_cus);         \
+        else if (nvp == 2) launch_v3<K, R, 2>(c, L, A3, basis, gbank, n_cus);    \
+        else launch_v3<K, R, 4>(c, L, A3, basis, gbank, n_cus);                  \
+        break;
+    switch (L.ksteps * 10 + L.layout) {
+        CASE3(1, 1) CASE3(2, 1) CASE3(3, 1) CASE3(4, 1)
+        CASE3(1, 2) CASE3(2, 2) CASE3(3, 2) CASE3(4, 2)
+        CASE3(3, 3)
+        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma3: unsupported size class");
+    }
+#undef CASE3
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+}  // namespace focr

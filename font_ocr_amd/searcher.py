@@ -15,6 +15,7 @@ from .bank import HIT_DTYPE, MATCH_DTYPE
 
 MAX_MATCHES = 1024  # src/ncc.rs:31
 SCAN_MFMA, SCAN_DIRECT, SCAN_RUST = 0, 1, 2
+PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE = 0, 1, 2
 
 
 class FocrError(RuntimeError):
@@ -163,7 +164,19 @@ class Scanner:
         self.upload_pages(luma, 0, invert)
 
     def scan(self, threshold=0.8, cap=MAX_MATCHES, mode=SCAN_MFMA):
+        """mode: SCAN_MFMA / SCAN_DIRECT / SCAN_RUST, or (SCAN_MFMA, PREFILTER_*) to pick the MFMA prefilter too."""
+        if isinstance(mode, tuple):
+            mode, prefilter = mode
+            self.set_prefilter(prefilter)
         self._ck(self._lib.focr_scan(self._h, float(threshold), int(cap), int(mode)))
+
+    def set_prefilter(self, prefilter):
+        """PREFILTER_AUTO / PREFILTER_ONE_STAGE / PREFILTER_TWO_STAGE (focr_ctx_set_prefilter); results never change."""
+        self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
+
+    def force_split(self, on):
+        """Test hook (focr_debug_force_split): scan the batch in page sub-ranges as after a candidate overflow."""
+        self._ck(self._lib.focr_debug_force_split(self._h, int(bool(on))))
 
     def set_scan_cus(self, max_cus):
         """Upper bound on the CUs the persistent scan kernel occupies (0 = all)."""

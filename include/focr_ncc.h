@@ -206,6 +206,16 @@ int focr_sync(focr_ctx_t *ctx);
  * section 5). */
 int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
 
+/* Which MFMA prefilter FOCR_SCAN_MFMA uses.  Results are identical in every mode (both are conservative filters in
+ * front of the same exact verify); only the speed differs.
+ *   AUTO       two stages where the bank compresses well (glyph banks do), else one
+ *   ONE_STAGE  every (window, template) pair pays its n_w*n_h taps in the int8 MFMA (scan_mfma2.hip)
+ *   TWO_STAGE  a low-rank bound over ALL templates first (int8 basis + one bf16 MFMA per 16x16 block), the exact-taps
+ *              int8 stage only on the blocks it cannot rule out (scan_mfma3.hip); falls back to ONE_STAGE for size
+ *              classes it does not cover */
+enum { FOCR_PREFILTER_AUTO = 0, FOCR_PREFILTER_ONE_STAGE = 1, FOCR_PREFILTER_TWO_STAGE = 2 };
+int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
+
 /* ---- batches in flight ---------------------------------------------------
  * The executor form of the page parallelism of src/ncc.rs:839-847 (rayon
  * par_iter over pages): n contexts on one device, one worker thread each;
@@ -267,6 +277,20 @@ size_t focr_last_launches(focr_ctx_t *ctx, focr_launch_info_t *out, size_t cap);
  * triples, so the f64 divide/sqrt rounding can be compared with the host's. */
 int focr_debug_rnorm(focr_ctx_t *ctx, const uint32_t *s, const uint64_t *s2, const uint32_t *n,
                      size_t n_items, double *out);
+
+/* Test hook: make focr_scan take its candidate-overflow fallback (the batch scanned in page sub-ranges and appended)
+ * without waiting for an overflow. */
+int focr_debug_force_split(focr_ctx_t *ctx, int on);
+
+/* Host model of the two-stage prefilter's bound (no device needed; used by the CPU tests): builds the low-rank data
+ * of the bank's first super-class exactly as focr_bank_upload does and evaluates, for n_windows caller-supplied
+ * frame-sized ink-high patches (frame_w * frame_h bytes each, row-major), the exact similarity of every template
+ * (double; NaN where the reference cannot emit) and the stage-2 value D2 the device computes (the flag is D2 > 0).
+ * info[8] = {available, r, n_cls, frame_w, frame_h, mean rho, max rho, inv_lambda}.  windows may be NULL to query
+ * info only. */
+int focr_debug_lowrank(const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
+                       size_t needles_len, const uint8_t *windows, size_t n_windows, float threshold,
+                       double *info, double *sim, float *d2);
 
 #ifdef __cplusplus
 }

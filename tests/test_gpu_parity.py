@@ -5,12 +5,16 @@ import pytest
 
 from font_ocr_amd import synth_page, synth_pages
 from font_ocr_amd.bank import SYNTH_SEED_BASE
-from font_ocr_amd.searcher import SCAN_DIRECT, SCAN_MFMA, Scanner, Searcher, text_of
+from font_ocr_amd.searcher import PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE, SCAN_DIRECT, SCAN_MFMA, Scanner, Searcher, text_of
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-MODES = [pytest.param(SCAN_DIRECT, id="direct"), pytest.param(SCAN_MFMA, id="mfma")]
+# the exact v_dot4 path and the MFMA path with each of its prefilters (one stage: every pair pays its taps in int8;
+# two stages: low-rank bound first, scan_mfma3.hip) — all three must reproduce the reference lists bit for bit
+MFMA1, MFMA2 = (SCAN_MFMA, PREFILTER_ONE_STAGE), (SCAN_MFMA, PREFILTER_TWO_STAGE)
+MODES = [pytest.param(SCAN_DIRECT, id="direct"), pytest.param((SCAN_MFMA, PREFILTER_ONE_STAGE), id="mfma1"),
+         pytest.param((SCAN_MFMA, PREFILTER_TWO_STAGE), id="mfma2")]
 
 
 @pytest.fixture(scope="module")
@@ -188,11 +192,15 @@ def test_full_size_c2_properties(scanner, bank_x2):
     scanner.set_bank(bank_x2)
     scanner.set_pages(pages)
     res = {}
-    for mode in (SCAN_DIRECT, SCAN_MFMA):
+    for mode in (SCAN_DIRECT, MFMA1, MFMA2):
         scanner.scan(0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
-    assert np.array_equal(res[SCAN_DIRECT][0], res[SCAN_MFMA][0])
-    assert res[SCAN_DIRECT][2].tobytes() == res[SCAN_MFMA][2].tobytes()
+        if mode != SCAN_DIRECT:
+            assert [li["name"][:10] for li in scanner.launches()] == ["scan_mfma2" if mode == MFMA1 else "scan_mfma3"]
+    for mode in (MFMA1, MFMA2):
+        assert np.array_equal(res[SCAN_DIRECT][0], res[mode][0])
+        assert res[SCAN_DIRECT][2].tobytes() == res[mode][2].tobytes()
+    res[SCAN_MFMA] = res[MFMA2]
     scanner.process_hits(0.95, 5)
     lines = scanner.lines()
     ok = tot = 0
@@ -238,21 +246,25 @@ def test_c3_geometry_1200x1600_vs_reference(scanner, bank_x2y2):
     pages = synth_pages(bank_x2y2, 4, r_w, r_h, first=3000)
     scanner.set_bank(bank_x2y2)
     scanner.set_pages(pages)
-    scanner.scan(0.8, 1024, SCAN_MFMA)
+    scanner.scan(0.8, 1024, MFMA2)
     res4 = (scanner.counts().copy(),) + scanner.matches()
+    assert all(li["name"].startswith("scan_mfma3") for li in scanner.launches()) and len(scanner.launches()) >= 2  # bank chunks
     _assert_equal_ref_batch(res4, pages, bank_x2y2, 0.8, 1024)
     assert res4[0].sum() > 400_000  # dense text: ~1e5 raw hits per page
-    scanner.scan(0.8, 1024, SCAN_DIRECT)
-    assert np.array_equal(scanner.counts(), res4[0]) and scanner.matches()[1].tobytes() == res4[2].tobytes()
+    for mode in (SCAN_DIRECT, MFMA1):
+        scanner.scan(0.8, 1024, mode)
+        assert np.array_equal(scanner.counts(), res4[0]) and scanner.matches()[1].tobytes() == res4[2].tobytes()
     scanner.process_hits(0.95, 5)
     lines4 = scanner.lines_flat().copy()
     # 64 pages, MFMA == direct; pages 0..3 of the batch are the four above
     big = np.concatenate([pages, synth_pages(bank_x2y2, 60, r_w, r_h, first=3004)])
     scanner.set_pages(big)
     res = {}
-    for mode in (SCAN_MFMA, SCAN_DIRECT):
+    for mode in (MFMA2, MFMA1, SCAN_DIRECT):
         scanner.scan(0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
+    res[SCAN_MFMA] = res[MFMA2]
+    assert np.array_equal(res[MFMA1][0], res[SCAN_DIRECT][0]) and res[MFMA1][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
     assert np.array_equal(res[SCAN_MFMA][0], res[SCAN_DIRECT][0])
     assert res[SCAN_MFMA][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
     assert np.array_equal(res[SCAN_MFMA][0][:4], res4[0])
@@ -276,13 +288,15 @@ def test_c5_256_template_gemm_variant(scanner, bank_x2):
     scanner.set_bank(bank)
     scanner.set_pages(pages)
     res = {}
-    for mode in (SCAN_MFMA, SCAN_DIRECT):
+    for mode in (MFMA1, MFMA2, SCAN_DIRECT):
         scanner.scan(0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
         names = [li["name"] for li in scanner.launches()]
-        assert any(n.startswith("scan_mfma2") for n in names) == (mode == SCAN_MFMA), names
-    assert np.array_equal(res[SCAN_MFMA][0], res[SCAN_DIRECT][0])
-    assert res[SCAN_MFMA][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
+        assert any(n.startswith("scan_mfma") for n in names) == (mode != SCAN_DIRECT), names
+    res[SCAN_MFMA] = res[MFMA2]
+    for mode in (MFMA1, MFMA2):
+        assert np.array_equal(res[mode][0], res[SCAN_DIRECT][0])
+        assert res[mode][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
     _assert_equal_ref_batch(res[SCAN_MFMA], pages, bank, 0.8, 1024)
     assert res[SCAN_MFMA][0].sum() > 50_000
 
@@ -390,7 +404,7 @@ def test_split_batch_fallback_equals_single_pass(scanner, bank_x2, mode, monkeyp
     scanner.set_pages(pages)
     out = {}
     for split in ("0", "1"):
-        monkeypatch.setenv("FOCR_FORCE_SPLIT", split)
+        scanner.force_split(split == "1")
         for thr, cap in ((0.8, 1024), (0.2, 50)):
             scanner.scan(thr, cap, mode)
             counts = scanner.counts().copy()
@@ -398,7 +412,7 @@ def test_split_batch_fallback_equals_single_pass(scanner, bank_x2, mode, monkeyp
             scanner.process_hits(0.9, 5)
             chars = scanner.lines_flat().copy()
             out[(split, thr)] = (counts, offsets.copy(), m.copy(), chars)
-    monkeypatch.setenv("FOCR_FORCE_SPLIT", "0")
+    scanner.force_split(False)
     for thr in (0.8, 0.2):
         a, b = out[("0", thr)], out[("1", thr)]
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -431,7 +445,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
     """Seeded fuzz over page geometry, bank shapes (all K layouts, class mixes), thresholds and caps; both device
     paths against the oracle, plus process_hits against the oracle's on the same lists."""
     rng = np.random.default_rng(20261004)
-    total_matches = total_chars = capped = 0
+    total_matches = total_chars = capped = two_stage = 0
     for it in range(150):
         n_classes = int(rng.integers(1, 4))
         shapes = [(int(rng.integers(1, 17)), int(rng.integers(1, 33))) for _ in range(n_classes)]
@@ -454,10 +468,11 @@ def test_fuzz_geometry_banks_thresholds(scanner):
         scanner.set_bank(bank)
         scanner.set_pages(pages)
         want = _oracle_lists(pages, bank, thr, cap)
-        for mode in (SCAN_MFMA, SCAN_DIRECT):
+        for mode in (MFMA1, MFMA2, SCAN_DIRECT):
             scanner.scan(thr, cap, mode)
             offsets, m = scanner.matches()
             _assert_same(_csr_to_lists(offsets, m, n_pages, len(bank)), want, f"fuzz {it} shapes={shapes} {r_w}x{r_h} thr={thr} cap={cap} mode={mode}")
+            two_stage += any(li["name"].startswith("scan_mfma3") for li in scanner.launches())
             total_matches += len(m)
             capped += int((scanner.counts() == cap).sum())
         scanner.process_hits(0.6, 3)
@@ -473,7 +488,8 @@ def test_fuzz_geometry_banks_thresholds(scanner):
                 assert np.array_equal(lg["x"].astype(np.int64), lw["x"].astype(np.int64)) and np.array_equal(lg["letter"], lw["letter"])
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
                 total_chars += len(lg)
-    assert total_matches > 20000 and total_chars > 500 and capped > 100, (total_matches, total_chars, capped)
+    assert total_matches > 30000 and total_chars > 500 and capped > 150, (total_matches, total_chars, capped)
+    assert two_stage >= 10, two_stage  # banks large enough for the two-stage prefilter did occur
 
 
 @pytest.mark.parametrize("mode", MODES)
