@@ -16,7 +16,7 @@
 //   Then  <a, t^> = sum_j y_j g_tj + <a - mean, e_t>  <=  sum_j y_j g_tj + R rho_t + N_F rho_par_t   (Cauchy-Schwarz),
 //   and the reference emits only if <a, t^> / norm_c > thr.  Hence  "reference emits  =>  D2 > 0":
 //   stage 2 has no false negatives; kappa_t carries rho_par_t plus explicit margins for the bf16 rounding of y
-//   (2^-9 sqrt(lambda_max) |g_t|) and the f32 accumulation inside the MFMA (see build()).
+//   (2^-8 sqrt(lambda_max) |g_t|) and the f32 accumulation inside the MFMA (see build()).
 //   Only the (16 windows x 16 templates) blocks with some D2 > 0 (about 7 % on text pages) go through the exact-taps int8
 //   stage of scan_mfma.hip, whose candidates are verified with the reference arithmetic as before.
 //
@@ -249,6 +249,14 @@ void build_lowrank(focr_ctx *c, SuperClass &su, const uint8_t *dense, std::vecto
     for (int j = 0; j < r; j++) slot_of[j] = lr_comp_slot((uint32_t)j, 2 + n_cls);
     const size_t g_base = g_bytes.size();
     g_bytes.resize(g_base + (size_t)su.n_tiles * 512, 0);  // 64 lanes x 8 bf16 per N-tile
+    // Padding slots and dead templates (constant needles) must never flag a block: an all-zero row would give D2 = +0.0,
+    // which the kernel's sign test counts as a flag.  -1 in the N_F slot makes their D2 = -N_F(w) < 0 on every window
+    // with any variance; live templates overwrite the whole row below.
+    {
+        const uint32_t slot = lr_extra_slot(1), b = slot / 16, gq = (slot % 16) / 4, v = slot % 4;
+        for (uint32_t nt = 0; nt < su.n_tiles; nt++)
+            for (uint32_t nn = 0; nn < 16; nn++) g_bytes[g_base + ((size_t)nt * 64 + gq * 16 + nn) * 8 + 4 * b + v] = 0xbf80u;
+    }
     std::vector<double> rhs(r), g(r), e(D), proj(r), coef(r);
     double rho_sum = 0, rho_max = 0;
     for (const Tv &t : tv) {

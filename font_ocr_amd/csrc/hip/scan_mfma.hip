@@ -496,12 +496,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         size_t norm_floats = 0;
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
-            if (!su.mtx || !su.lr.available || c->prefilter == FOCR_PREFILTER_ONE_STAGE) continue;
+            if (!su.mtx || !su.lr.available || su.ksteps > 4 || c->prefilter == FOCR_PREFILTER_ONE_STAGE) continue;
             const uint32_t nv = su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0);
             if (nv > (uint32_t)LR_MAX_VALUES) continue;
-            // AUTO: worth it when the bank compresses (mean residual of the unit templates) and there are enough N-tiles
-            // for the saved taps to outweigh the 2 basis tiles + the bf16 pass
-            if (c->prefilter == FOCR_PREFILTER_AUTO && !(su.lr.mean_rho < 0.45 && su.n_tiles >= 8)) continue;
+            // AUTO takes the one-stage prefilter: measured at BASELINE configs[1] the two-stage kernel issues 45 % fewer
+            // MFMA cycles but ends up instruction-issue-bound (3 VALU per 16x16 block for the sign test + the mid stage), 2.33 ms
+            // against 2.30 ms — it is kept as a tested alternative, not as the default
+            if (c->prefilter != FOCR_PREFILTER_TWO_STAGE) continue;
             two[si] = 1;
             norm_nv[si] = nv;
             norm_off[si] = norm_floats;

@@ -168,6 +168,31 @@ __device__ __forceinline__ uint32_t pack_bf16_bits(uint32_t hi_f32_bits, uint32_
     return __builtin_amdgcn_perm(hi_f32_bits, lo_f32_bits, 0x07060302u);  // {hi[31:16], lo[31:16]}
 }
 
+#ifdef FOCR_MFMA3_PROF
+// experiment builds only (make hip EXTRA=-DFOCR_MFMA3_PROF): per-phase wave cycles, summed over all waves
+__device__ unsigned long long focr_prof[8];
+#define PROF_STAMP(i)                                        \
+    {                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        prof_acc[i] += now_ - prof_t;                        \
+        prof_t = now_;                                       \
+    }
+#else
+#define PROF_STAMP(i)
+#endif
+
+// wave64 AND-reduction via DPP (row_shr 1/2/4/8 inside the rows of 16, row_bcast 15/31 across them); lanes without a
+// source keep the identity ~0.  The result is uniform (read from lane 63).
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) {
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false);
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false);
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false);
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false);
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false);
+    v &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int KSTEPS, int RPG, int MT, int NW, int NV>
 __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
@@ -204,7 +229,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
     const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
     const uint32_t stride = xc_blocks * NW;
     const uint32_t n_extras = 2 + P.n_cls;
+    // segments (size classes) of the launch: at most LR_MAX_CLASSES, boundaries and norm-value indices as scalars
+    const uint32_t seg_end0 = segs.n > 0 ? segs.s[0].tile_end : 0xffffffffu, seg_end1 = segs.n > 1 ? segs.s[1].tile_end : 0xffffffffu;
+    const uint32_t seg_end2 = segs.n > 2 ? segs.s[2].tile_end : 0xffffffffu;
+    const uint32_t seg_val0 = P.seg_value[0], seg_val1 = P.seg_value[1], seg_val2 = P.seg_value[2], seg_val3 = P.seg_value[3];
+    float kq_of_value[NV];  // threshold scale of the exact-taps stage per norm value (= per class of the super-class)
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        kq_of_value[v] = 0.f;
+#pragma unroll
+        for (int sg = 0; sg < (int)LR_MAX_CLASSES; sg++)
+            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) kq_of_value[v] = P.kq[sg];
+    }
 
+#ifdef FOCR_MFMA3_PROF
+    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
@@ -257,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): every int8 operand row sums to zero
             }
         }
+        PROF_STAMP(0)
         // ---- stage 1: y = basis x windows^T ----
         v4i y[MT][LR_BASIS_TILES];
 #pragma unroll
@@ -270,6 +311,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
                 for (int mt = 0; mt < MT; mt++) y[mt][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(uf, afrag[mt][ks], y[mt][b], 0, 0, 0);
             }
         }
+        PROF_STAMP(1)
         // ---- mid: bf16 operand of stage 2 ----
         v4i zf[MT];
 #pragma unroll
@@ -322,69 +364,132 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
             zf[mt] = v4i{(int)__builtin_bit_cast(uint32_t, p01), (int)__builtin_bit_cast(uint32_t, p23), (int)__builtin_bit_cast(uint32_t, p45),
                          (int)(hi7 | lo6)};
         }
-        // ---- stage 2: D2[template][window] per (M-tile, N-tile); set bit nt of the M-tile's mask if any D2 > 0 ----
+        PROF_STAMP(2)
+        // ---- stage 2: D2[template][window] per (M-tile, N-tile); bit nt of the M-tile's mask <=> some D2 > 0 ----
+        // No compare, no scalar traffic in the loop: the sign bit of max3(d0, d1, d2) & d3 (integer view: set iff all four
+        // are negative) is shifted into a per-M-tile register, 32 N-tiles per register; one wave-wide AND per M-tile and
+        // 32 N-tiles then tells which blocks have a non-negative value in some lane.  (+0.0 counts as a flag: harmless.)
         uint64_t mask[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) mask[mt] = 0;
-        for (uint32_t nt = 0; nt < n_tiles16; nt++) {
-            const v8bf gq = __builtin_bit_cast(v8bf, gb[nt * 64 + lane]);
+        v4i gq = gb[lane];
+        auto tile_signs = [&](const v4i gop, uint32_t (&sbr)[MT]) {  // one N-tile: MT MFMAs, their sign bits shifted in
             v4f d[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
-                d[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq, __builtin_bit_cast(v8bf, zf[mt]), v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                d[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, gop), __builtin_bit_cast(v8bf, zf[mt]), v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const float m = __builtin_fmaxf(__builtin_fmaxf(d[mt][0], d[mt][1]), __builtin_fmaxf(d[mt][2], d[mt][3]));
-                const uint64_t any = __builtin_amdgcn_ballot_w64(m > 0.f);
-                mask[mt] |= (uint64_t)(any != 0) << nt;
+                const v4i di = __builtin_bit_cast(v4i, d[mt]);
+                const int m3 = max(max(di[0], di[1]), di[2]) & di[3];  // only its sign is used: set iff all four are negative
+                sbr[mt] = __builtin_amdgcn_alignbit(sbr[mt], (uint32_t)m3, 31);  // (sb << 1) | sign
+            }
+        };
+        for (uint32_t nt0 = 0; nt0 < n_tiles16; nt0 += 32) {
+            const uint32_t nblk = min(32u, n_tiles16 - nt0), last = n_tiles16 - 1;
+            uint32_t sb[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) sb[mt] = 0xffffffffu;
+            for (uint32_t k = 0; k < nblk; k += 2) {  // two N-tiles per trip: the operands ping-pong between two register sets
+                const v4i g1 = gb[min(nt0 + k + 1, last) * 64 + lane];
+                tile_signs(gq, sb);
+                gq = gb[min(nt0 + k + 2, last) * 64 + lane];
+                if (k + 1 < nblk) tile_signs(g1, sb);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const uint32_t all_neg = wave_and(sb[mt]);  // bit j: tile nt0 + nblk - 1 - j is negative in every lane
+                const uint32_t flagged = __builtin_bitreverse32(~all_neg) >> (32 - nblk);  // bit k: tile nt0 + k
+                mask[mt] |= (uint64_t)flagged << nt0;
             }
         }
+        PROF_STAMP(3)
         // ---- stage 3: exact-taps int8 check of the flagged (M-tile, N-tile) blocks ----
+        // Two blocks of an M-tile per step (independent accumulator chains hide each other's LDS and MFMA latency; an odd
+        // last block is paired with itself and its copy ignored).
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             uint64_t m = pv[mt] ? mask[mt] : 0;  // M-tiles past the end of the enumeration never flag
-            while (m) {
-                const uint32_t nt = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                uint32_t sgi = 0;
-                while (sgi + 1 < segs.n && nt >= segs.s[sgi].tile_end) sgi++;  // the block's size class
-                float nc = 0.f;
+            if (m == 0) continue;
+            // C-in of the lane's own window per size class of the launch: -(floor(kq * norm_c) - 2) (scan_mfma.hip:
+            // conservative for |L| < 4e6), or -REJECT where the class never emits
+            int cin[NV];
 #pragma unroll
-                for (int v = 0; v < NV; v++) nc = ((uint32_t)v == P.seg_value[sgi]) ? nrm[mt][v] : nc;
-                // C-in = -(floor(kq * norm_c) - 2) of the lane's own window (scan_mfma.hip: conservative for |L| < 4e6), or
-                // -REJECT where the class never emits
-                float Lf = __builtin_floorf(P.kq[sgi] * nc) - 2.0f;
+            for (int v = 0; v < NV; v++) {
+                const float nc = nrm[mt][v];
+                float Lf = __builtin_floorf(kq_of_value[v] * nc) - 2.0f;
                 Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-                const int cin = nc > 0.f ? -(int)Lf : -REJECT;
-                v4i acc = v4i{cin, cin, cin, cin};
+                cin[v] = nc > 0.f ? -(int)Lf : -REJECT;
+            }
+            while (m) {
+                const uint32_t nta = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const bool two = m != 0;
+                const uint32_t ntb = two ? (uint32_t)__builtin_ctzll(m) : nta;
+                m &= m - 1;  // (0 & anything) stays 0
+#ifdef FOCR_MFMA3_PROF
+                prof_acc[5] += two ? 2 : 1;
+#endif
+                // the blocks' size classes: segment boundaries and their norm values are launch constants in SGPRs
+                const uint32_t va = nta < seg_end0 ? seg_val0 : nta < seg_end1 ? seg_val1 : nta < seg_end2 ? seg_val2 : seg_val3;
+                const uint32_t vb = ntb < seg_end0 ? seg_val0 : ntb < seg_end1 ? seg_val1 : ntb < seg_end2 ? seg_val2 : seg_val3;
+                int ca = cin[0], cb = cin[0];
 #pragma unroll
-                for (int ks = 0; ks < KSTEPS; ks++)
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bank[(nt * KSTEPS + ks) * 64 + lane], afrag[mt][ks], acc, 0, 0, 0);
-                const int mm = max(max(acc[0], acc[1]), max(acc[2], acc[3]));
+                for (int v = 1; v < NV; v++) {
+                    ca = va == (uint32_t)v ? cin[v] : ca;
+                    cb = vb == (uint32_t)v ? cin[v] : cb;
+                }
+                v4i acca = v4i{ca, ca, ca, ca}, accb = v4i{cb, cb, cb, cb};
+                v4i ba[KSTEPS], bb[KSTEPS];
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++) {
+                    ba[ks] = bank[(nta * KSTEPS + ks) * 64 + lane];
+                    bb[ks] = bank[(ntb * KSTEPS + ks) * 64 + lane];
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++) {
+                    acca = __builtin_amdgcn_mfma_i32_16x16x64_i8(ba[ks], afrag[mt][ks], acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_i32_16x16x64_i8(bb[ks], afrag[mt][ks], accb, 0, 0, 0);
+                }
+                if (!two) accb = v4i{-1, -1, -1, -1};
+                const int mm = max(max(max(acca[0], acca[1]), max(acca[2], acca[3])), max(max(accb[0], accb[1]), max(accb[2], accb[3])));
                 if (__builtin_amdgcn_ballot_w64(mm > 0) == 0) continue;  // wave-uniform
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bool f = acc[i] > 0;
-                    const uint64_t fm = __builtin_amdgcn_ballot_w64(f);
-                    if (!fm) continue;  // wave-uniform
-                    // lane (r, g), register i: template 4g + i of the tile, window px + r
-                    const uint32_t tg = f ? tg_lds[nt * 16 + 4 * g + i] : 0xffffffffu;
-                    const bool ok = tg != 0xffffffffu;  // dead / padding templates never emit
-                    const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
-                    if (!cnt) continue;
-                    if (wcount + cnt > WBUF) {
-                        flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
-                        wcount = 0;
+                for (int h = 0; h < 2; h++) {
+                    const v4i acc = h ? accb : acca;
+                    const uint32_t nt = h ? ntb : nta;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool f = acc[i] > 0;
+                        const uint64_t fm = __builtin_amdgcn_ballot_w64(f);
+                        if (!fm) continue;  // wave-uniform
+                        // lane (r, g), register i: template 4g + i of the tile, window px + r
+                        const uint32_t tg = f ? tg_lds[nt * 16 + 4 * g + i] : 0xffffffffu;
+                        const bool ok = tg != 0xffffffffu;  // dead / padding templates never emit
+                        const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
+                        if (!cnt) continue;
+                        if (wcount + cnt > WBUF) {
+                            flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                            wcount = 0;
+                        }
+                        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
+                        if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pp[mt], py[mt], px[mt] + r, tg);
+                        wcount += cnt;
                     }
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
-                    if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pp[mt], py[mt], px[mt] + r, tg);
-                    wcount += cnt;
                 }
             }
         }
+        PROF_STAMP(4)
     }
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+#ifdef FOCR_MFMA3_PROF
+    if (lane == 0)
+    {
+        for (int i = 0; i < 6; i++) atomicAdd(&focr_prof[i], prof_acc[i]);
+        atomicAdd(&focr_prof[6], (unsigned long long)((item_end > xc * per_xc + slot * NW + w) ? (item_end - (xc * per_xc + slot * NW + w) + stride - 1) / stride : 0));
+    }
+#endif
 }
 
 template <int KSTEPS, int RPG, int NV>
@@ -410,6 +515,17 @@ static void launch_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, con
                        c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
     c->launch_end();
 }
+
+#ifdef FOCR_MFMA3_PROF
+extern "C" int focr_debug_prof(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(focr_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(focr_prof), z, sizeof z);
+    }
+    return 0;
+}
+#endif
 
 int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus) {
     const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);

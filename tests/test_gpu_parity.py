@@ -451,7 +451,11 @@ def test_fuzz_geometry_banks_thresholds(scanner):
         shapes = [(int(rng.integers(1, 17)), int(rng.integers(1, 33))) for _ in range(n_classes)]
         if it % 4 == 0:
             shapes = [(int(rng.integers(8, 13)), int(rng.choice([14, 15, 16]))) for _ in range(n_classes)]  # font-like
-        bank = _random_bank(rng, shapes, int(rng.integers(1, 24)))
+        per_shape = int(rng.integers(1, 24))
+        if it % 5 == 1:  # banks with enough templates per K layout for the two-stage prefilter to engage
+            shapes = [(int(rng.integers(9, 13)), int(rng.choice([13, 15, 16]))) for _ in range(n_classes)]
+            per_shape = int(rng.integers(40, 90))
+        bank = _random_bank(rng, shapes, per_shape)
         n_pages = int(rng.integers(1, 5))
         r_w = int(rng.integers(max(s[0] for s in shapes) + 1, 150))
         r_h = int(rng.integers(max(s[1] for s in shapes) + 1, 90))

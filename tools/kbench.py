@@ -9,6 +9,8 @@ bank = Bank.load(os.path.join(ROOT, "tests/golden/bank_dejavu13_ascii95_x2.bin")
 P = int(os.environ.get("KB_PAGES", "128"))
 pages = synth_pages(bank, P, 608, 720)
 sc = Scanner(0); sc.set_bank(bank); sc.set_pages(pages)
+sc.set_prefilter(int(os.environ.get("KB_PREFILTER", "0")))
+if os.environ.get("KB_SCAN_CUS"): sc.set_scan_cus(int(os.environ["KB_SCAN_CUS"]))
 for _ in range(2): sc.scan(0.8, 1024, SCAN_MFMA)
 acc = {}
 N = 5
@@ -16,4 +18,4 @@ for _ in range(N):
     sc.scan(0.8, 1024, SCAN_MFMA)
     for li in sc.launches(): acc[li["name"]] = acc.get(li["name"], 0) + li["ms"] / N
 t = sc.timings(); c = sc.counters()
-print(os.environ.get("FOCR_MFMA_DBG", "0"), {k: round(v, 3) for k, v in acc.items()}, {k: round(v, 3) for k, v in t.items()}, c["candidates"], c["raw_hits"])
+print("prefilter", os.environ.get("KB_PREFILTER", "0"), {k: round(v, 3) for k, v in acc.items()}, {k: round(v, 3) for k, v in t.items()}, c["candidates"], c["raw_hits"])
