@@ -258,7 +258,7 @@ int focr_ctx_set_scan_cus(focr_ctx_t *c, unsigned max_cus) {
 }
 
 int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
-    if (!c || mode < FOCR_PREFILTER_AUTO || mode > FOCR_PREFILTER_TWO_STAGE) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
+    if (!c || mode < FOCR_PREFILTER_AUTO || mode > FOCR_PREFILTER_LEGACY) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
     c->prefilter = mode;
     return FOCR_OK;
 }

@@ -402,7 +402,7 @@ extern "C" int focr_debug_lowrank(const focr_template_t *templates, size_t n_tem
     auto up16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0xffffu) >> 16); };
     for (size_t wi = 0; wi < n_windows; wi++) {
         const uint8_t *a = windows + wi * D;
-        // window norms of every class box and of the frame, as stats_lr_kernel computes them (f32)
+        // window norms of every class box and of the frame, as the statistics kernel computes them (f32)
         float nrm[LR_MAX_CLASSES + 1];
         double norm_exact[LR_MAX_CLASSES + 1];
         for (uint32_t v = 0; v <= lr.n_cls; v++) {

@@ -85,14 +85,6 @@ struct MfmaLaunch {
 // flag in the sign (> 0: the reference can emit there: x, y >= 1, window inside the page, variance > 0; <= 0: never);
 // when no class has the frame's box, one more value holds the frame norm.  |value| is always the norm.
 constexpr int LR_MAX_VALUES = 4;
-struct StatsLR {
-    uint32_t nwid, nv, n_cls, maxh;
-    uint32_t wid[4];                 // distinct box widths
-    uint32_t v_wid[LR_MAX_VALUES];   // per value: index into wid[]
-    uint32_t v_w[LR_MAX_VALUES], v_h[LR_MAX_VALUES], v_n[LR_MAX_VALUES];
-    float v_rn[LR_MAX_VALUES];       // 1 / n
-};
-
 // Stage-2 K slots (LR_K = 32): slot = 16 b + 4 g + v lives in lane group g, element 4 b + v of the 8-element bf16
 // operand.  The 2 + n_cls "extras" (R, N_F, one threshold slot per class) sit at compile-time element positions so the
 // kernel places them with a select on the lane group only: extra e < 4 -> element 7 of lane group e, extra e >= 4 ->
@@ -123,11 +115,9 @@ struct Mfma3Args {
 // scan_mfma3.hip
 uint32_t mfma3_chunk_tiles(uint32_t ksteps);
 int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus);
-int launch_stats_lr(focr_ctx *c, const SuperClass &su, const StatsLR &P, float *norms, size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
-                    uint8_t *live, uint32_t mtx, uint32_t n_rows);
-
 // scan_mfma2.hip
 size_t mfma2_bank_budget();
+int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus);  // roles swapped, norms instead of negL
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);
 
 }  // namespace focr

@@ -53,11 +53,15 @@ int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims
 constexpr int STX = 64, STY = 32, SLDW = 21;
 static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h - 1) * (SLDW * 4 + STX * 4 + STX * 2); }
 
-template <int NDW, bool SMALLN>
+// NORMS: instead of the int32 threshold the kernel stores the window norm sqrt(V / n) as f32 (kq = 1 / n), its sign
+// carrying the emit flag (mfma_common.h, "window norms"): the C-in is then formed inside the scan kernel from it
+// (scan_mfma2s_kernel, scan_mfma3_kernel).  mark = 0: a box that is no size class (the two-stage prefilter's frame):
+// plain norms, no live-tile marks.
+template <int NDW, bool SMALLN, bool NORMS>
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                     uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, float kq,
                                                     int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows,
-                                                    uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
+                                                    uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t mark) {
     // dynamic LDS, sized for this class's n_h (stats_lds_bytes): ~21 KB at n_h = 15 -> 7 blocks per CU; the kernel
     // lives on that occupancy (global-load latency, two barriers per tile)
     extern __shared__ uint32_t stats_lds[];
@@ -135,9 +139,15 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             float Lf = __builtin_floorf(kq * __builtin_amdgcn_sqrtf(Vf)) - 2.0f;
             Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
             const bool emit = x_ok && y >= 1 && y + n_h <= r_h && nz;
-            const int32_t out = emit ? -(int32_t)Lf : -REJECT;
+            int32_t out = emit ? -(int32_t)Lf : -REJECT;
+            if (NORMS) {
+                // norm = sqrt(V / n): relative error < 4 * 2^-24 (conversion, product with the rounded 1/n, 1-ulp sqrt)
+                float nrm = __builtin_amdgcn_sqrtf(Vf * kq);
+                if (mark && !emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
+                out = __float_as_int(nrm);
+            }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(emit);
-            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
+            if (mark && mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
             out_p[(size_t)k * Lpitch] = out;
         }
         if (k + 1 < PER) {  // slide down one row
@@ -418,10 +428,32 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                            (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
-                           n_rows);
+                           n_rows, 1u);
     };
-    if (sc.n_w * sc.n_h <= 256) launch(stats_kernel<NDW, true>);
-    else launch(stats_kernel<NDW, false>);
+    if (sc.n_w * sc.n_h <= 256) launch(stats_kernel<NDW, true, false>);
+    else launch(stats_kernel<NDW, false, false>);
+}
+
+// window norms of one box (a size class: mark = 1, or the two-stage prefilter's frame: mark = 0) into one plane of d_norms
+static int launch_norms(focr_ctx *c, uint32_t n_w, uint32_t n_h, float *plane, uint32_t Lpitch, uint32_t Lrows, uint8_t *live, uint32_t mtx,
+                        uint32_t n_rows, uint32_t mark) {
+    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
+    const float rn = 1.0f / (float)(n_w * n_h);
+    const bool small = n_w * n_h <= 256;
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, n_w, n_h, rn, reinterpret_cast<int32_t *>(plane), Lpitch, Lrows, live,
+                           mtx, n_rows, mark);
+    };
+    switch ((n_w + 3) / 4) {
+        case 1: small ? launch(stats_kernel<1, true, true>) : launch(stats_kernel<1, false, true>); break;
+        case 2: small ? launch(stats_kernel<2, true, true>) : launch(stats_kernel<2, false, true>); break;
+        case 3: small ? launch(stats_kernel<3, true, true>) : launch(stats_kernel<3, false, true>); break;
+        case 4: small ? launch(stats_kernel<4, true, true>) : launch(stats_kernel<4, false, true>); break;
+        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported box width");
+    }
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
 }
 
 // Process-wide hand-over of the scan kernel between contexts of one device (events are never destroyed).
@@ -437,7 +469,10 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
     const uint32_t Lpitch = (uint32_t)((c->r_w + 63) / 64 * 64 + 64), Lrows = (uint32_t)((c->r_h + 7) / 8 * 8 + 8);
     const size_t L_per_class = c->n_pages * (size_t)Lrows * Lpitch;
-    const size_t L_bytes = L_per_class * c->classes.size() * sizeof(int32_t);
+    // the per-class int32 threshold tables are only needed by super-classes on the legacy path
+    bool need_L = false;
+    for (const SuperClass &su : c->supers) need_L |= su.ksteps > 4 || su.classes.size() > (size_t)LR_MAX_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY;
+    const size_t L_bytes = need_L ? L_per_class * c->classes.size() * sizeof(int32_t) : 0;
     if (c->L_bytes < L_bytes) {
         FOCR_HIP(c, hipStreamSynchronize(c->stream));
         if (c->d_L) (void)hipFree(c->d_L);
@@ -494,19 +529,24 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         std::vector<size_t> norm_off(c->supers.size(), 0);
         std::vector<uint32_t> norm_nv(c->supers.size(), 0);
         size_t norm_floats = 0;
+        // two[si]: 0 = legacy path (per-class int32 negL tables, scan_mfma2_kernel: > 4 K-steps or > 4 size classes),
+        //          1 = window norms (one fused statistics pass) + scan_mfma2s_kernel (one stage, roles swapped),
+        //          2 = window norms + scan_mfma3_kernel (two stages)
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
-            if (!su.mtx || !su.lr.available || su.ksteps > 4 || c->prefilter == FOCR_PREFILTER_ONE_STAGE) continue;
-            const uint32_t nv = su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0);
-            if (nv > (uint32_t)LR_MAX_VALUES) continue;
+            if (!su.mtx || su.ksteps > 4 || su.classes.size() > (size_t)LR_MAX_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY) continue;
+            uint32_t nv = (uint32_t)su.classes.size();
+            two[si] = 1;
             // AUTO takes the one-stage prefilter: measured at BASELINE configs[1] the two-stage kernel issues 45 % fewer
             // MFMA cycles but ends up instruction-issue-bound (3 VALU per 16x16 block for the sign test + the mid stage), 2.33 ms
             // against 2.30 ms — it is kept as a tested alternative, not as the default
-            if (c->prefilter != FOCR_PREFILTER_TWO_STAGE) continue;
-            two[si] = 1;
+            if (c->prefilter == FOCR_PREFILTER_TWO_STAGE && su.lr.available && su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0) <= (uint32_t)LR_MAX_VALUES) {
+                two[si] = 2;
+                nv = su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0);
+            }
             norm_nv[si] = nv;
             norm_off[si] = norm_floats;
-            norm_floats += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernel is instantiated for 1 / 2 / 4 values
+            norm_floats += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernels are instantiated for 1 / 2 / 4 values
         }
         if (c->norms_bytes < norm_floats * 4) {
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
@@ -519,25 +559,15 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            if (two[si]) {  // one fused pass: the norms of every class box and of the frame
-                StatsLR P{};
-                P.n_cls = su.lr.n_cls;
-                P.nv = norm_nv[si];
-                for (uint32_t v = 0; v < P.nv; v++) {
-                    const uint32_t bw = v < P.n_cls ? c->classes[su.classes[v]].n_w : su.lr.frame_w;
-                    const uint32_t bh = v < P.n_cls ? c->classes[su.classes[v]].n_h : su.lr.frame_h;
-                    uint32_t wi = 0;
-                    for (; wi < P.nwid; wi++)
-                        if (P.wid[wi] == bw) break;
-                    if (wi == P.nwid) P.wid[P.nwid++] = bw;
-                    P.v_wid[v] = wi;
-                    P.v_w[v] = bw;
-                    P.v_h[v] = bh;
-                    P.v_n[v] = bw * bh;
-                    P.v_rn[v] = 1.0f / (float)(bw * bh);
-                    P.maxh = std::max(P.maxh, bh);
+            if (two[si]) {  // window norms: one plane per size class (+ the frame's, if no class has its box)
+                for (uint32_t v = 0; v < norm_nv[si]; v++) {
+                    const bool is_class = v < su.classes.size();
+                    const uint32_t bw = is_class ? c->classes[su.classes[v]].n_w : su.lr.frame_w;
+                    const uint32_t bh = is_class ? c->classes[su.classes[v]].n_h : su.lr.frame_h;
+                    if ((rc = launch_norms(c, bw, bh, c->d_norms + norm_off[si] + (size_t)v * plane, Lpitch, Lrows, live + su.live_offset, su.mtx, su.n_rows,
+                                           is_class ? 1u : 0u)))
+                        return rc;
                 }
-                if ((rc = launch_stats_lr(c, su, P, c->d_norms + norm_off[si], plane, Lpitch, Lrows, live + su.live_offset, su.mtx, su.n_rows))) return rc;
             } else {
                 for (uint32_t k : su.classes) {
                     const SizeClass &sc = c->classes[k];
@@ -579,7 +609,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            const uint32_t chunk_tiles = two[si] ? mfma3_chunk_tiles(su.ksteps) : (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
+            const uint32_t chunk_tiles = two[si] == 2 ? mfma3_chunk_tiles(su.ksteps) : (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
             uint32_t t0 = 0;
             while (t0 < su.n_tiles) {
                 MfmaLaunch L{};
@@ -633,7 +663,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
                 const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
-                if (two[si]) {
+                if (two[si] == 1) {
+                    A3.norms = c->d_norms + norm_off[si];
+                    A3.norm_stride = plane;
+                    A3.nv = norm_nv[si];
+                    A3.n_cls = (uint32_t)su.classes.size();
+                    if ((rc = dispatch_mfma_v2s(c, L, A3, cus))) return rc;
+                } else if (two[si] == 2) {
                     A3.norms = c->d_norms + norm_off[si];
                     A3.norm_stride = plane;
                     A3.nv = norm_nv[si];

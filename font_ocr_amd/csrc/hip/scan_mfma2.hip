@@ -193,6 +193,215 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same one-stage prefilter with the operand roles swapped: (A = templates, B = windows), so D[template][window] puts
+// window px + r on lane (r, g) for all four accumulator registers.  The C-in of a lane is then the threshold of its OWN
+// window: one f32 norm per size class and M-tile stays in a register for the whole item (stats_lr_kernel's planar
+// norms, scan_mfma3.hip) and the int32 threshold -(floor(kq * norm) - 2) is formed from it once per item — no per-class
+// int32 table, no reload of C-in rows in the middle of the N-tile loop when the size class changes.
+template <int KSTEPS, int RPG, int MT, int NW, int NV>
+__global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2s_kernel(
+    const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
+    const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
+    const Mfma3Args P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    v4i *bank = reinterpret_cast<v4i *>(smem);
+    const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + (size_t)bank_vec * 16 + (size_t)NW * WBUF * 8);
+    for (uint32_t i = threadIdx.x; i < bank_vec; i += NW * 64) bank[i] = qbank[i];
+    for (uint32_t i = threadIdx.x; i < n_tiles16 * 16; i += NW * 64) tg_lds[i] = tglobal[i];
+    __syncthreads();  // the only barrier
+
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint64_t *wbuf = reinterpret_cast<uint64_t *>(smem + (size_t)bank_vec * 16) + w * WBUF;
+    uint32_t wcount = 0;
+
+    const uint32_t total_mt = *live_count;
+    const uint32_t n_items = (total_mt + MT - 1) / MT;
+    const uint32_t n_xc = min(8u, gridDim.x);
+    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
+    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;
+    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
+    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
+    const uint32_t stride = xc_blocks * NW;
+    float kq_of_value[NV];  // threshold scale per norm value (= per size class of the super-class)
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        kq_of_value[v] = 0.f;
+#pragma unroll
+        for (int sg = 0; sg < (int)LR_MAX_CLASSES; sg++)
+            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) kq_of_value[v] = P.kq[sg];
+    }
+
+    v4i afrag[MT][KSTEPS];
+    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
+        const uint32_t m0 = item * MT;
+        uint32_t px[MT], py[MT], pp[MT];
+        bool pv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            pv[mt] = m0 + mt < total_mt;
+            const uint64_t e = live_list[pv[mt] ? m0 + mt : total_mt - 1];
+            px[mt] = 16 * (uint32_t)(e & 0xfff);
+            py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
+            pp[mt] = (uint32_t)(e >> 32);
+        }
+        float nrm[MT][NV];  // norms of the lane's own window px + r, one per size class
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const float *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+#pragma unroll
+            for (int v = 0; v < NV; v++) nrm[mt][v] = np[(size_t)v * P.norm_stride];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                v4i a;
+                if (RPG == LAYOUT_W16) {
+                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)(4 * ks + g) * pitch);
+                } else if (RPG == LAYOUT_W8) {
+                    const uint8_t *p0 = base + (size_t)(2 * (4 * ks + g)) * pitch;
+                    const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
+                    a = v4i{lo[0], lo[1], hi[0], hi[1]};
+                } else {
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
+                    if (ks % 3 == 0) {
+                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
+                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
+                        a = v4i{t[0], t[1], t[2], u};
+                    } else if (ks % 3 == 1) {
+                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
+                        a = v4i{t[0], t[1], u[0], u[1]};
+                    } else {
+                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
+                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
+                        a = v4i{t, u[0], u[1], u[2]};
+                    }
+                }
+                afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): the quantised templates sum to zero
+            }
+        }
+        // C-in of the lane's own window per size class: -(floor(kq * norm_c) - 2) (scan_mfma.hip: conservative for
+        // |L| < 4e6), -REJECT where the class never emits (the statistics kernel flags that in the sign) or past the enumeration
+        int cin[MT][NV];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const float nc = nrm[mt][v];
+                float Lf = __builtin_floorf(kq_of_value[v] * nc) - 2.0f;
+                Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+                cin[mt][v] = (nc > 0.f && pv[mt]) ? -(int)Lf : -REJECT;
+            }
+        v4i bf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) bf[ks] = bank[ks * 64 + lane];
+        uint32_t nt = 0;
+        for (uint32_t sgi = 0; sgi < segs.n; sgi++) {  // one segment = the N-tiles of one size class
+            const uint32_t seg_end = segs.s[sgi].tile_end, sv = P.seg_value[sgi];
+            int ci[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                ci[mt] = cin[mt][0];
+#pragma unroll
+                for (int v = 1; v < NV; v++) ci[mt] = sv == (uint32_t)v ? cin[mt][v] : ci[mt];
+            }
+            for (; nt < seg_end; nt++) {
+                v4i acc[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[mt] = v4i{ci[mt], ci[mt], ci[mt], ci[mt]};
+                const uint32_t nxt = nt + 1 < n_tiles16 ? nt + 1 : nt;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+                        acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[ks], afrag[mt][ks], acc[mt], 0, 0, 0);
+                    bf[ks] = bank[(nxt * KSTEPS + ks) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);  // pin the re-load here (see scan_mfma2_kernel)
+                }
+                int m = max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3]));
+#pragma unroll
+                for (int mt = 1; mt < MT; mt++) {
+                    m = max(max(m, acc[mt][0]), acc[mt][1]);
+                    m = max(max(m, acc[mt][2]), acc[mt][3]);
+                }
+                if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
+                        if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const bool f = acc[mt][i] > 0;
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(f);
+                            if (!mask) continue;  // wave-uniform
+                            // lane (r, g), register i: template 4g + i of the tile, window px + r
+                            const uint32_t tg = f ? tg_lds[nt * 16 + 4 * g + i] : 0xffffffffu;
+                            const bool ok = tg != 0xffffffffu;  // dead / padding templates never emit
+                            const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+                            const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
+                            if (!cnt) continue;
+                            if (wcount + cnt > WBUF) {
+                                flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                                wcount = 0;
+                            }
+                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
+                            uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
+                            asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
+                            if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pg, yy, xx + r, tg);
+                            wcount += cnt;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+}
+
+template <int KSTEPS, int RPG, int NV>
+static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
+    constexpr int MT = 4, NW = 16;
+    const uint32_t n_tiles16 = L.n_tiles16;
+    const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
+    const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;
+    const uint64_t n_items = (total_mt + MT - 1) / MT;
+    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
+    auto kern = scan_mfma2s_kernel<KSTEPS, RPG, MT, NW, NV>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint64_t issued = 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;  // per live M-tile; scaled by the live count after the scan
+    char name[64];
+    snprintf(name, sizeof name, "scan_mfma2s_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
+    c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
+                       L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
+    c->launch_end();
+}
+
+int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
+    const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);
+#define CASE2S(K, R)                                            \
+    case (K) * 10 + (R):                                        \
+        if (nvp == 1) launch_v2s<K, R, 1>(c, L, A3, n_cus);     \
+        else if (nvp == 2) launch_v2s<K, R, 2>(c, L, A3, n_cus); \
+        else launch_v2s<K, R, 4>(c, L, A3, n_cus);              \
+        break;
+    switch (L.ksteps * 10 + L.layout) {
+        CASE2S(1, 1) CASE2S(2, 1) CASE2S(3, 1) CASE2S(4, 1)
+        CASE2S(1, 2) CASE2S(2, 2) CASE2S(3, 2) CASE2S(4, 2)
+        CASE2S(3, 3)
+        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma2s: unsupported size class");
+    }
+#undef CASE2S
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
 template <int KSTEPS, int RPG, int MT, int NW>
 static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     const uint32_t n_tiles16 = L.n_tiles16;

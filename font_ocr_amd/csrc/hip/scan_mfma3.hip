@@ -15,7 +15,7 @@
 //             (A = templates, B = windows), so the C-in of lane (r, g) is the threshold of its own window for all four
 //             registers: -(floor(kq * norm_c) - 2), from the norm the lane already holds.  Survivors are candidates.
 //
-// Window norms come from stats_lr_kernel below (one fused pass per super-class: all size classes + the frame).
+// Window norms come from scan_mfma.hip's stats_kernel<.., NORMS = true> (one plane per size class, one for the frame).
 #include <algorithm>
 
 #include "mfma_common.h"
@@ -31,128 +31,6 @@ typedef int int_u __attribute__((aligned(1)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-
-// ---------------------------------------------------------------------------------------------
-// window norms of a super-class: separable sliding sums as in scan_mfma.hip's stats_kernel, all boxes in one pass
-constexpr int STX = 64, STY = 32, SLDW = 21;
-static inline size_t stats_lr_lds_bytes(const StatsLR &P) {
-    const size_t rows = STY + P.maxh - 1;
-    return rows * (SLDW * 4 + (size_t)P.nwid * STX * 6);
-}
-
-template <bool SMALLN>
-__global__ __launch_bounds__(256) void stats_lr_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
-                                                       uint32_t r_w, uint32_t r_h, const StatsLR P, float *__restrict__ norms,
-                                                       size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
-                                                       uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
-    extern __shared__ uint32_t slr_lds[];
-    const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
-    const uint32_t rows = STY + P.maxh - 1;
-    uint32_t (*tile)[SLDW] = reinterpret_cast<uint32_t (*)[SLDW]>(slr_lds);
-    uint32_t *H2 = slr_lds + rows * SLDW;                                                // [wid][row][STX] u32
-    uint16_t *H = reinterpret_cast<uint16_t *>(slr_lds + rows * SLDW + P.nwid * rows * STX);  // [wid][row][STX] u16 (<= 16 * 255)
-    const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
-    for (uint32_t i = threadIdx.x; i < rows * SLDW; i += 256) {
-        uint32_t r = i / SLDW, cdw = i % SLDW;
-        uint32_t gy = y0 + r, gx = x0 + cdw * 4;
-        uint32_t v = 0;
-        if (gy < rows_alloc && gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t *>(pg + (size_t)gy * pitch + gx);
-        tile[r][cdw] = v;
-    }
-    __syncthreads();
-    {  // horizontal sums of every distinct width
-        const uint32_t lane = threadIdx.x & 63, cb = lane >> 2, sh = lane & 3;
-        for (uint32_t r = threadIdx.x >> 6; r < rows; r += 4) {
-            uint32_t w4[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) w4[k] = __builtin_amdgcn_alignbyte(tile[r][cb + k + 1], tile[r][cb + k], sh);
-            for (uint32_t wi = 0; wi < P.nwid; wi++) {
-                const uint32_t n_w = P.wid[wi];
-                uint32_t h = 0, h2 = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
-                    const uint32_t w = w4[k] & keep;
-                    h = __builtin_amdgcn_udot4(w, 0x01010101u, h, false);
-                    h2 = __builtin_amdgcn_udot4(w, w, h2, false);
-                }
-                H[(wi * rows + r) * STX + lane] = (uint16_t)h;
-                H2[(wi * rows + r) * STX + lane] = h2;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t col = threadIdx.x & 63, strip = threadIdx.x >> 6;
-    const uint32_t x = x0 + col;
-    if (x >= Lpitch) return;
-    constexpr uint32_t PER = STY / 4;
-    const uint32_t r0 = strip * PER;
-    uint32_t s[LR_MAX_VALUES], s2[LR_MAX_VALUES];
-#pragma unroll
-    for (int v = 0; v < LR_MAX_VALUES; v++) {
-        s[v] = s2[v] = 0;
-        if ((uint32_t)v < P.nv) {
-            const uint32_t base = P.v_wid[v] * rows;
-            for (uint32_t j = 0; j < P.v_h[v]; j++) {
-                s[v] += H[(base + r0 + j) * STX + col];
-                s2[v] += H2[(base + r0 + j) * STX + col];
-            }
-        }
-    }
-    const uint32_t ya = y0 + r0;
-    const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
-    const size_t live_i = ((size_t)page * n_rows + ya) * mtx + (x >> 4);
-#pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t y = ya + k;
-        if (y < Lrows) {
-            bool any_emit = false;
-#pragma unroll
-            for (int v = 0; v < LR_MAX_VALUES; v++) {
-                if ((uint32_t)v < P.nv) {
-                    // V = n*s2 - s*s, exact; V > 0 <=> the reference's rnorm is finite (src/ncc.rs:309-311)
-                    float Vf;
-                    if (SMALLN) Vf = (float)(P.v_n[v] * s2[v] - s[v] * s[v]);
-                    else Vf = (float)((uint64_t)P.v_n[v] * s2[v] - (uint64_t)s[v] * s[v]);
-                    // norm = sqrt(V / n): relative error < 4 * 2^-24 (conversion, product with the rounded 1/n, 1-ulp sqrt)
-                    float nrm = __builtin_amdgcn_sqrtf(Vf * P.v_rn[v]);
-                    if ((uint32_t)v < P.n_cls) {
-                        // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
-                        const bool emit = x >= 1 && x + P.v_w[v] <= r_w && y >= 1 && y + P.v_h[v] <= r_h && Vf > 0.f;
-                        any_emit |= emit;
-                        if (!emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
-                    }
-                    norms[(size_t)v * norm_stride + ((size_t)page * Lrows + y) * Lpitch + x] = nrm;
-                    if (k + 1 < PER) {  // slide down one row
-                        const uint32_t base = P.v_wid[v] * rows;
-                        s[v] += H[(base + r0 + k + P.v_h[v]) * STX + col] - H[(base + r0 + k) * STX + col];
-                        s2[v] += H2[(base + r0 + k + P.v_h[v]) * STX + col] - H2[(base + r0 + k) * STX + col];
-                    }
-                }
-            }
-            const uint64_t lm = __builtin_amdgcn_ballot_w64(any_emit);
-            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
-        }
-    }
-}
-
-int launch_stats_lr(focr_ctx *c, const SuperClass &su, const StatsLR &P, float *norms, size_t norm_stride, uint32_t Lpitch, uint32_t Lrows,
-                    uint8_t *live, uint32_t mtx, uint32_t n_rows) {
-    (void)su;
-    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
-    bool small = true;
-    for (uint32_t v = 0; v < P.nv; v++) small &= P.v_n[v] <= 256;
-    const size_t lds = stats_lr_lds_bytes(P);
-    auto launch = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
-                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, P, norms, norm_stride, Lpitch, Lrows, live, mtx, n_rows);
-    };
-    if (small) launch(stats_lr_kernel<true>);
-    else launch(stats_lr_kernel<false>);
-    FOCR_HIP(c, hipGetLastError());
-    return FOCR_OK;
-}
 
 // ---------------------------------------------------------------------------------------------
 constexpr size_t V3_LDS_TOTAL = 160 << 10;

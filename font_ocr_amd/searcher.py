@@ -15,7 +15,7 @@ from .bank import HIT_DTYPE, MATCH_DTYPE
 
 MAX_MATCHES = 1024  # src/ncc.rs:31
 SCAN_MFMA, SCAN_DIRECT, SCAN_RUST = 0, 1, 2
-PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE = 0, 1, 2
+PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE, PREFILTER_LEGACY = 0, 1, 2, 3
 
 
 class FocrError(RuntimeError):

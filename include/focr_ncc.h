@@ -213,7 +213,13 @@ int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
  *   TWO_STAGE  a low-rank bound over ALL templates first (int8 basis + one bf16 MFMA per 16x16 block), the exact-taps
  *              int8 stage only on the blocks it cannot rule out (scan_mfma3.hip); falls back to ONE_STAGE for size
  *              classes it does not cover */
-enum { FOCR_PREFILTER_AUTO = 0, FOCR_PREFILTER_ONE_STAGE = 1, FOCR_PREFILTER_TWO_STAGE = 2 };
+enum {
+    FOCR_PREFILTER_AUTO = 0,
+    FOCR_PREFILTER_ONE_STAGE = 1,
+    FOCR_PREFILTER_TWO_STAGE = 2,
+    FOCR_PREFILTER_LEGACY = 3 /* ONE_STAGE through round 1's kernel and its per-class int32 threshold tables (what size
+                               * classes with more than 4 K-steps always use); kept selectable as a cross-check */
+};
 int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
 
 /* ---- batches in flight ---------------------------------------------------
