@@ -110,6 +110,7 @@ HIP_SYMBOLS = {
     "focr_ctx_set_scan_cus": (C.c_int, [C.c_void_p, C.c_uint]),
     "focr_ctx_set_prefilter": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_debug_force_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "focr_ctx_set_size_estimates": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_debug_lowrank": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_float,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "focr_pipe_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),

@@ -105,6 +105,23 @@ struct focr_ctx {
     int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
     int8_t *d_lr_basis = nullptr;               // two-stage prefilter: int8 basis rows (per-lane MFMA layout), all super-classes
     uint16_t *d_lr_g = nullptr;                 // two-stage prefilter: bf16 stage-2 operand, 1 KiB per N-tile
+    // ---- result sizes (ctx.hip: finish_results) ----
+    // Every phase after the scan kernel takes its element count from device memory; the host only supplies upper bounds for
+    // grids and buffers.  Exact mode reads the counts between the phases (as round 1 did); estimated mode (same bank,
+    // geometry, threshold, cap as the previous scan) bounds them by the previous scan's counts + 20 %, launches everything
+    // without waiting, and reads all sizes once at the end; a count above its bound redoes the batch in exact mode.
+    uint64_t *d_res = nullptr;   // [0] candidates [1] hits [2] matches [3] lines << 32 | chars [4] overflow flag [7] scratch count
+    uint64_t *h_res = nullptr;   // pinned copy
+    uint32_t *h_live = nullptr;  // pinned copy of the live M-tile counts (d_counter + 8 ..), 40 entries
+    const uint64_t *d_n_hits = nullptr;  // device-side number of hits of the last scan
+    size_t ub_hits = 0;                  // the bound its buffers were sized for
+    uint64_t n_hits_raw_u64 = 0;
+    bool sizes_pending = false, post_pending = false, estimated = false, estimates_enabled = true;
+    size_t est_cand = 0, est_hits = 0, ub_cand = 0;
+    uint64_t est_sig = 0, bank_gen = 0, counters_redone = 0;
+    float scan_thr = 0.f, post_anchor = 0.f;
+    int scan_mode = 0;
+    int32_t post_overlap = 0;
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
     int prefilter = 0;                          // FOCR_PREFILTER_*: auto / single stage / two stages (focr_ctx_set_prefilter)
     float *d_norms = nullptr;                   // two-stage path: window norms [super-class][page][Lrows][Lpitch][n_cls (+1)] f32
@@ -207,6 +224,7 @@ int launch_scan_direct(focr_ctx *ctx, float threshold, int rust_formula);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
+int finish_results(focr_ctx *c);  // wait for the stream once and read the result sizes of the last scan / process_hits
 int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
 void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
                        std::vector<uint32_t> &direct, std::vector<uint8_t> &dense);

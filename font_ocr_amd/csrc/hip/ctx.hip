@@ -185,7 +185,7 @@ void focr_ctx::launches_collect() {
 extern "C" {
 
 size_t focr_last_launches(focr_ctx_t *c, focr_launch_info_t *out, size_t cap) {
-    if (!c) return 0;
+    if (!c || finish_results(c) != FOCR_OK) return 0;
     for (size_t i = 0; out && i < c->launches.size() && i < cap; i++) out[i] = c->launches[i];
     return c->launches.size();
 }
@@ -223,6 +223,12 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
         FOCR_HIP(c, hipMalloc(&c->d_counter, 64 * sizeof(uint32_t)));
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        FOCR_HIP(c, hipMalloc((void **)&c->d_res, 8 * sizeof(uint64_t)));
+        FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 8 * sizeof(uint64_t), c->stream));
+        FOCR_HIP(c, hipHostMalloc((void **)&c->h_res, 8 * sizeof(uint64_t), hipHostMallocDefault));
+        FOCR_HIP(c, hipHostMalloc((void **)&c->h_live, 40 * sizeof(uint32_t), hipHostMallocDefault));
+        memset(c->h_res, 0, 8 * sizeof(uint64_t));
+        memset(c->h_live, 0, 40 * sizeof(uint32_t));
         return FOCR_OK;
     };
     int rc = init();
@@ -243,6 +249,9 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     free_dev(c->d_pages);
     free_dev(c->d_stage);
     free_dev(c->d_counter);
+    free_dev(c->d_res);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_live) (void)hipHostFree(c->h_live);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->launch_events)
@@ -273,7 +282,7 @@ int focr_sync(focr_ctx_t *c) {
     if (!c) return FOCR_ERR_INVALID;
     FOCR_HIP(c, hipSetDevice(c->device));
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    return FOCR_OK;
+    return finish_results(c);
 }
 
 int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
@@ -293,6 +302,8 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
     free_bank(c);
     c->scanned = c->processed = false;
+    c->sizes_pending = c->post_pending = false;
+    c->bank_gen++;
     std::vector<uint32_t> direct;
     std::vector<uint8_t> dense;
     bank_host_prepare(c, templates, n_templates, needles, direct, dense);
@@ -440,6 +451,7 @@ static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count,
                        c->rows_alloc, first, count, invert);
     FOCR_HIP(c, hipGetLastError());
     c->scanned = c->processed = false;
+    c->sizes_pending = c->post_pending = false;  // results of the previous batch are gone with its pages
     return FOCR_OK;
 }
 
@@ -554,6 +566,12 @@ static int scan_split(focr_ctx *c, Run &run) {
         c->matches_alloc = acc_cap;
         c->d_hkeys = (uint64_t *)c->acc_hkeys.p;
         c->d_hsims = (float *)c->acc_hsims.p;
+        // the accumulated hit count as the device-side value process_hits reads
+        c->n_hits_raw_u64 = hit_total;
+        FOCR_HIP(c, hipMemcpyAsync(c->d_res + 7, &c->n_hits_raw_u64, 8, hipMemcpyHostToDevice, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        c->d_n_hits = c->d_res + 7;
+        c->ub_hits = hit_total;
     }
     c->sub_p0 = 0;
     c->sub_np = c->n_pages;
@@ -568,6 +586,99 @@ static int scan_split(focr_ctx *c, Run &run) {
     return FOCR_OK;
 }
 
+namespace focr {
+
+// The whole scan pipeline on the resident batch with the parameters stored in the context (focr_scan, and the redo of a
+// batch whose estimated sizes turned out too small).
+static int scan_now(focr_ctx *c) {
+    const float threshold = c->scan_thr;
+    const int mode = c->scan_mode;
+    c->scanned = c->processed = false;
+    c->sizes_pending = c->post_pending = false;
+    for (auto &m : c->ms) m = 0.f;
+    c->counters[3] = 0;
+    auto run = [&](size_t p0, size_t np) -> int {  // the whole pipeline on pages [p0, p0 + np)
+        c->sub_p0 = p0;
+        c->sub_np = np;
+        c->ordered = false;
+        int r = mode == FOCR_SCAN_MFMA ? launch_scan_mfma(c, threshold) : launch_scan_direct(c, threshold, mode == FOCR_SCAN_RUST);
+        if (r) return r;
+        if (!c->ordered && (r = order_hits(c))) return r;
+        c->sizes_pending = true;
+        return c->estimated ? FOCR_OK : finish_results(c);  // exact sizes: the counts are read here, as they always were
+    };
+    // focr_debug_force_split (tests): take the split-batch path without waiting for an overflow
+    int rc = c->force_split ? FOCR_ERR_OVERFLOW : run(0, c->n_pages);
+    if (rc == FOCR_ERR_OVERFLOW || rc == FOCR_ERR_NOMEM) {
+        // Too many candidates for one pass (very low thresholds): scan the batch in page sub-ranges and append the
+        // results.  Only hits that survive the per-call cap are kept, so the totals stay bounded by pages x T x cap.
+        c->estimated = false;
+        c->sizes_pending = false;
+        rc = scan_split(c, run);
+        if (rc) return rc;
+    } else if (rc) {
+        return rc;
+    }
+    c->scanned = true;
+    return FOCR_OK;
+}
+
+int finish_results(focr_ctx *c) {
+    if (!c->sizes_pending && !c->post_pending) return FOCR_OK;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->sizes_pending) {
+        c->sizes_pending = false;
+        const uint64_t n_cand = c->h_res[0], n_hits = c->h_res[1], total = c->h_res[2];
+        if (c->estimated && (c->h_res[4] & 1)) {
+            // a count exceeded the bound taken from the previous scan: redo this batch with exact sizes (and its
+            // process_hits, if that was queued behind it)
+            const bool redo_post = c->post_pending;
+            c->post_pending = false;
+            c->estimated = false;
+            c->est_cand = c->est_hits = 0;
+            c->counters_redone++;
+            int rc = scan_now(c);
+            if (rc) return rc;
+            return redo_post ? focr_process_hits(c, c->post_anchor, c->post_overlap) : FOCR_OK;
+        }
+        if (c->scan_mode == FOCR_SCAN_MFMA) {
+            c->n_cand = (size_t)n_cand;
+            c->counters[0] = n_cand;
+            FOCR_HIP(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
+            FOCR_HIP(c, hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]));
+            FOCR_HIP(c, hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[3]));
+            c->counters[3] = 0;
+            for (focr_launch_info_t &li : c->launches) {  // issued MACs follow the number of live M-tiles (known only now)
+                if (strncmp(li.name, "scan_mfma", 9) == 0 && (li.n_templates >> 24) < 40) {
+                    li.issued_macs *= c->h_live[li.n_templates >> 24];
+                    li.n_templates &= 0xffffff;
+                }
+                c->counters[3] += li.issued_macs;
+            }
+            c->launches_collect();
+            // bounds for the next scan of the same setup: this scan's counts + 20 %
+            c->est_cand = (size_t)n_cand + (size_t)n_cand / 5 + 32768;
+            c->est_hits = (size_t)n_hits + (size_t)n_hits / 5 + 32768;
+        }
+        c->counters[1] = n_hits;
+        c->n_hits = c->n_hits_raw = (size_t)n_hits;
+        c->n_matches = (size_t)total;
+        FOCR_HIP(c, hipEventElapsedTime(&c->ms[3], c->ev[3], c->ev[4]));
+        FOCR_HIP(c, hipEventElapsedTime(&c->ms[5], c->ev[0], c->ev[4]));
+    }
+    if (c->post_pending) {
+        c->post_pending = false;
+        const uint64_t tot = c->h_res[3];
+        c->n_lines = (size_t)(tot >> 32);
+        c->n_chars = (size_t)(tot & 0xffffffffu);
+        FOCR_HIP(c, hipEventElapsedTime(&c->ms[4], c->ev[5], c->ev[6]));
+    }
+    return FOCR_OK;
+}
+
+}  // namespace focr
+
 extern "C" {
 
 int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
@@ -579,8 +690,8 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     if (std::isnan(threshold)) threshold = INFINITY;  // `sim > NaN` is never true in the reference (src/ncc.cpp:362-366): no hits
     FOCR_HIP(c, hipSetDevice(c->device));
     c->cap = cap;
-    c->scanned = c->processed = false;
-    for (auto &m : c->ms) m = 0.f;
+    c->scan_thr = threshold;
+    c->scan_mode = mode;
     // algorithmic MACs, SURVEY.md section 8(d): true template area x searched windows
     uint64_t macs = 0;
     for (const SizeClass &sc : c->classes) {
@@ -589,49 +700,47 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         macs += wx * wy * (uint64_t)sc.n_w * sc.n_h * sc.n_templates;
     }
     c->counters[2] = macs * c->n_pages;
-    c->counters[3] = 0;
     auto nbits = [](size_t n) {
         uint32_t b = 1;
         while (((size_t)1 << b) < n) b++;
         return b;
     };
     c->fmt = KeyFmt{nbits(c->n_templates), nbits(c->r_w), nbits(c->r_h), nbits(c->n_pages)};
-    auto run = [&](size_t p0, size_t np) -> int {  // the whole pipeline on pages [p0, p0 + np)
-        c->sub_p0 = p0;
-        c->sub_np = np;
-        c->ordered = false;
-        int r = mode == FOCR_SCAN_MFMA ? launch_scan_mfma(c, threshold) : launch_scan_direct(c, threshold, mode == FOCR_SCAN_RUST);
-        if (r) return r;
-        return c->ordered ? FOCR_OK : order_hits(c);
-    };
-    // focr_debug_force_split (tests): take the split-batch path without waiting for an overflow
-    int rc = c->force_split ? FOCR_ERR_OVERFLOW : run(0, c->n_pages);
-    if (rc == FOCR_ERR_OVERFLOW || rc == FOCR_ERR_NOMEM) {
-        // Too many candidates for one pass (very low thresholds): scan the batch in page sub-ranges and append the
-        // results.  Only hits that survive the per-call cap are kept, so the totals stay bounded by pages x T x cap.
-        rc = scan_split(c, run);
-        if (rc) return rc;
-    } else if (rc) {
-        return rc;
-    }
-    c->scanned = true;
+    // Size estimates are reused only for the very same setup (bank, batch geometry, threshold, cap, prefilter)
+    uint32_t tb;
+    memcpy(&tb, &threshold, 4);
+    uint64_t sig = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)c->bank_gen, (uint64_t)c->n_pages, (uint64_t)c->r_w, (uint64_t)c->r_h, (uint64_t)tb, (uint64_t)cap, (uint64_t)mode,
+                       (uint64_t)c->prefilter})
+        sig = (sig ^ v) * 1099511628211ull;
+    if (sig != c->est_sig) c->est_cand = c->est_hits = 0;
+    c->est_sig = sig;
+    c->estimated = c->estimates_enabled && mode == FOCR_SCAN_MFMA && !c->force_split && c->est_cand != 0;
+    return scan_now(c);
+}
+
+int focr_ctx_set_size_estimates(focr_ctx_t *c, int on) {
+    if (!c) return FOCR_ERR_INVALID;
+    c->estimates_enabled = on != 0;
     return FOCR_OK;
 }
 
 int focr_get_counts(focr_ctx_t *c, uint32_t *counts) {
     if (!c || !counts) return fail(c, FOCR_ERR_INVALID, "focr_get_counts: bad arguments");
     if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_get_counts: no scan results");
+    if (int rc = finish_results(c)) return rc;
     FOCR_HIP(c, hipSetDevice(c->device));
     FOCR_HIP(c, hipMemcpyAsync(counts, c->d_seg_count, c->n_pages * c->n_templates * 4, hipMemcpyDeviceToHost, c->stream));
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
     return FOCR_OK;
 }
 
-size_t focr_total_matches(focr_ctx_t *c) { return (c && c->scanned) ? c->n_matches : 0; }
+size_t focr_total_matches(focr_ctx_t *c) { return (c && c->scanned && finish_results(c) == FOCR_OK) ? c->n_matches : 0; }
 
 int focr_get_matches(focr_ctx_t *c, uint64_t *offsets, focr_match_t *matches) {
     if (!c) return FOCR_ERR_INVALID;
     if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_get_matches: no scan results");
+    if (int rc = finish_results(c)) return rc;
     FOCR_HIP(c, hipSetDevice(c->device));
     if (offsets)
         FOCR_HIP(c, hipMemcpyAsync(offsets, c->d_seg_offset, (c->n_pages * c->n_templates + 1) * 8, hipMemcpyDeviceToHost,
@@ -645,12 +754,14 @@ int focr_get_matches(focr_ctx_t *c, uint64_t *offsets, focr_match_t *matches) {
 
 int focr_last_timings(focr_ctx_t *c, float ms[6]) {
     if (!c || !ms) return FOCR_ERR_INVALID;
+    if (int rc = finish_results(c)) return rc;
     for (int i = 0; i < 6; i++) ms[i] = c->ms[i];
     return FOCR_OK;
 }
 
 int focr_last_counters(focr_ctx_t *c, uint64_t out[4]) {
     if (!c || !out) return FOCR_ERR_INVALID;
+    if (int rc = finish_results(c)) return rc;
     for (int i = 0; i < 4; i++) out[i] = c->counters[i];
     return FOCR_OK;
 }

@@ -69,6 +69,7 @@ static void lane_main(PipeLane *L) {
         }
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
         if (rc == FOCR_OK && job.post) rc = focr_process_hits(c, job.anchor_threshold, job.overlap);
+        if (rc == FOCR_OK) rc = focr_sync(c);  // the batch's one host wait: scan and process_hits queue everything without waiting
         if (rc == FOCR_OK && job.post && job.chars_out) {  // copy-out on the context's own stream: ordered, no other queue involved
             const size_t bytes = focr_total_chars(c) * sizeof(focr_hit_t);
             if (bytes > job.chars_cap) {

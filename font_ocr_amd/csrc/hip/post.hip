@@ -16,6 +16,7 @@
 namespace focr {
 
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
+int finish_results(focr_ctx *c);
 
 __device__ __forceinline__ int32_t total_key(float f) {  // f32::total_cmp as a signed-int order
     int32_t b = __float_as_int(f);
@@ -25,9 +26,10 @@ __device__ __forceinline__ int32_t total_key(float f) {  // f32::total_cmp as a 
 // (1) keep_y: rows with a kept hit of similarity >= anchor_threshold; also the extent of every (page, row) line in
 // the sorted hit list (one thread per hit looks at its neighbours), so that the line walk needs no search.
 __global__ void mark_anchor_rows(const uint64_t *__restrict__ hkeys, const float *__restrict__ hsims, const uint8_t *__restrict__ keep,
-                                 size_t n, KeyFmt fmt, float anchor, uint32_t r_h, uint8_t *__restrict__ keep_row,
+                                 const uint64_t *__restrict__ n_p, uint64_t ub, KeyFmt fmt, float anchor, uint32_t r_h, uint8_t *__restrict__ keep_row,
                                  uint32_t *__restrict__ line_b, uint32_t *__restrict__ line_e) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)min(*n_p, ub);  // device-side count, clamped to what the grid and buffers were sized for
     if (i >= n) return;
     const uint64_t k = hkeys[i];
     const size_t row = (size_t)fmt.page(k) * r_h + fmt.y(k);
@@ -113,14 +115,14 @@ __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ k
 }
 
 // one thread per hit slot: slot i of a row is the row's (i - line_b)-th output character if the row has that many groups
-__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, size_t n, KeyFmt fmt, uint32_t r_h,
+__global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__restrict__ sims, const uint64_t *__restrict__ n_p, uint64_t ub, KeyFmt fmt, uint32_t r_h,
                            const uint8_t *__restrict__ keep_row, const uint32_t *__restrict__ line_b,
                            const uint32_t *__restrict__ choice, const uint64_t *__restrict__ row_groups,
                            const uint64_t *__restrict__ scanned, const uint32_t *__restrict__ t_w,
                            const uint32_t *__restrict__ t_h, const uint32_t *__restrict__ t_letter,
                            uint64_t *__restrict__ line_char_off, focr_hit_t *__restrict__ chars) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= min(*n_p, ub)) return;
     const uint64_t ki = keys[i];
     const size_t row = (size_t)fmt.page(ki) * r_h + fmt.y(ki);
     if (!keep_row[row]) return;
@@ -144,11 +146,10 @@ __global__ void emit_chars(const uint64_t *__restrict__ keys, const float *__res
 }
 
 // page_line_off[p] = number of kept lines on pages < p = the row scan at the page's first row
-__global__ void page_offsets(const uint64_t *__restrict__ scanned, uint32_t r_h, uint64_t total_lines, uint32_t n_pages,
-                             uint64_t *__restrict__ page_line_off) {
+__global__ void page_offsets(const uint64_t *__restrict__ scanned, uint32_t r_h, uint32_t n_pages, uint64_t *__restrict__ page_line_off) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_pages) return;
-    page_line_off[p] = p < n_pages ? (scanned[(size_t)p * r_h] >> 32) : total_lines;
+    page_line_off[p] = scanned[(size_t)min(p, n_pages) * r_h] >> 32;  // p == n_pages: the scan's grand total
 }
 
 }  // namespace focr
@@ -163,56 +164,62 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     FOCR_HIP(c, hipSetDevice(c->device));
     c->processed = false;
     c->lines_on_host = false;
-    const size_t n = c->n_hits, n_pages = c->n_pages;  // all hits in (page, y, x, t) order; d_keep marks the capped ones
+    c->post_anchor = anchor_threshold;
+    c->post_overlap = overlap;
     c->n_chars = c->n_lines = 0;
-    if (n == 0 || c->n_matches == 0) {  // the reference panics on an empty hit list (src/ncc.rs:1040); we return zero lines
+    // all hits in (page, y, x, t) order; d_keep marks the ones that survive their call's cap.  Their number lives on the
+    // device (c->d_n_hits); `ub` is what the scan sized its buffers for (the exact count unless the scan ran on estimates)
+    const size_t ub = c->ub_hits, n_pages = c->n_pages;
+    if (!c->sizes_pending && (c->n_hits == 0 || c->n_matches == 0)) {  // the reference panics on an empty hit list (src/ncc.rs:1040); we return zero lines
         c->processed = true;
         c->ms[4] = 0.f;
         return FOCR_OK;
     }
-    if (n >= 0xffffffffull) return fail(c, FOCR_ERR_OVERFLOW, "focr_process_hits: more than 2^32 hits in one batch");
+    if (ub >= 0xffffffffull) return fail(c, FOCR_ERR_OVERFLOW, "focr_process_hits: more than 2^32 hits in one batch");
     FOCR_HIP(c, hipEventRecord(c->ev[5], c->stream));
-    // grow-only device scratch (no allocation in the steady state)
+    // grow-only device scratch (no allocation in the steady state); outputs are sized by their bounds: characters <= hits,
+    // lines <= page rows
     const size_t n_rows_total = n_pages * c->r_h;
     uint8_t *keep_row = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
-    uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, n * 4);
+    uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, (ub + 1) * 4);
     uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, (n_rows_total + 1) * 8);    // per row: 1<<32 | groups
     uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, (n_rows_total + 1) * 8);
     uint64_t *d_page_off = (uint64_t *)c->post_page_off.ensure(c, (n_pages + 1) * 8);
     uint32_t *line_b = (uint32_t *)c->post_line_be.ensure(c, n_rows_total * 8), *line_e = line_b ? line_b + n_rows_total : nullptr;
-    if (!line_b || !keep_row || !choice || !packed || !scanned || !d_page_off) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
+    uint64_t *d_line_off = (uint64_t *)c->post_line_off.ensure(c, (n_rows_total + 1) * 8);
+    focr_hit_t *d_chars = (focr_hit_t *)c->post_chars.ensure(c, (ub + 1) * sizeof(focr_hit_t));
+    if (!line_b || !keep_row || !choice || !packed || !scanned || !d_page_off || !d_line_off || !d_chars)
+        return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
     const uint8_t *keep = (const uint8_t *)c->ord_keep.p;
     FOCR_HIP(c, hipMemsetAsync(keep_row, 0, n_rows_total, c->stream));
     FOCR_HIP(c, hipMemsetAsync(packed, 0, (n_rows_total + 1) * 8, c->stream));
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, n, c->fmt, anchor_threshold,
-                       (uint32_t)c->r_h, keep_row, line_b, line_e);
+    const unsigned nb = (unsigned)((ub + 255) / 256);
+    if (ub)
+        hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, c->d_n_hits, (uint64_t)ub, c->fmt,
+                           anchor_threshold, (uint32_t)c->r_h, keep_row, line_b, line_e);
     hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
                        keep, c->fmt, (uint32_t)n_rows_total, overlap, keep_row, line_b, line_e, choice, packed);
     int rc;
     if ((rc = exclusive_scan_u64(c, packed, scanned, n_rows_total + 1))) return rc;
-    uint64_t tot = 0;  // packed[n_rows_total] = 0, so the scan's last entry is the grand total
-    FOCR_HIP(c, hipMemcpyAsync(&tot, scanned + n_rows_total, 8, hipMemcpyDeviceToHost, c->stream));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    c->n_lines = (size_t)(tot >> 32);
-    c->n_chars = (size_t)(tot & 0xffffffffu);
-    uint64_t *d_line_off = (uint64_t *)c->post_line_off.ensure(c, (c->n_lines + 1) * 8);
-    focr_hit_t *d_chars = (focr_hit_t *)c->post_chars.ensure(c, (c->n_chars ? c->n_chars : 1) * sizeof(focr_hit_t));
-    if (!d_line_off || !d_chars) return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
-    hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, n, c->fmt, (uint32_t)c->r_h, keep_row,
-                       line_b, choice, packed, scanned, c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
+    // packed[n_rows_total] = 0, so the scan's last entry is the grand total (lines << 32 | characters): into the result block
+    FOCR_HIP(c, hipMemcpyAsync(c->h_res + 3, scanned + n_rows_total, 8, hipMemcpyDeviceToHost, c->stream));
+    if (ub)
+        hipLaunchKernelGGL(emit_chars, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, c->d_n_hits, (uint64_t)ub, c->fmt, (uint32_t)c->r_h,
+                           keep_row, line_b, choice, packed, scanned, c->d_t_w, c->d_t_h, c->d_t_letter, d_line_off, d_chars);
     hipLaunchKernelGGL(page_offsets, dim3((unsigned)((n_pages + 1 + 255) / 256)), dim3(256), 0, c->stream, scanned, (uint32_t)c->r_h,
-                       (uint64_t)c->n_lines, (uint32_t)n_pages, d_page_off);
+                       (uint32_t)n_pages, d_page_off);
     FOCR_HIP(c, hipGetLastError());
     FOCR_HIP(c, hipEventRecord(c->ev[6], c->stream));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    FOCR_HIP(c, hipEventElapsedTime(&c->ms[4], c->ev[5], c->ev[6]));
+    c->post_pending = true;
     c->processed = true;
+    if (!c->sizes_pending) return finish_results(c);  // exact sizes: complete now, as the call always did
     return FOCR_OK;
 }
 
 // results stay in HBM until somebody asks for them
 static int fetch_lines(focr_ctx *c) {
+    int rc0 = finish_results(c);
+    if (rc0) return rc0;
     if (c->lines_on_host) return FOCR_OK;
     c->h_page_line_off.assign(c->n_pages + 1, 0);
     c->h_line_char_off.assign(c->n_lines + 1, 0);
@@ -231,8 +238,8 @@ static int fetch_lines(focr_ctx *c) {
     return FOCR_OK;
 }
 
-size_t focr_total_chars(focr_ctx_t *c) { return (c && c->processed) ? c->n_chars : 0; }
-size_t focr_total_lines(focr_ctx_t *c) { return (c && c->processed) ? c->n_lines : 0; }
+size_t focr_total_chars(focr_ctx_t *c) { return (c && c->processed && finish_results(c) == FOCR_OK) ? c->n_chars : 0; }
+size_t focr_total_lines(focr_ctx_t *c) { return (c && c->processed && finish_results(c) == FOCR_OK) ? c->n_lines : 0; }
 
 int focr_get_lines(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *line_char_offsets, focr_hit_t *chars) {
     if (!c) return FOCR_ERR_INVALID;
@@ -246,7 +253,7 @@ int focr_get_lines(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *line_ch
 }
 
 const focr_hit_t *focr_lines_device_chars(focr_ctx_t *c) {
-    return (c && c->processed && c->n_chars) ? (const focr_hit_t *)c->post_chars.p : nullptr;
+    return (c && c->processed && finish_results(c) == FOCR_OK && c->n_chars) ? (const focr_hit_t *)c->post_chars.p : nullptr;
 }
 
 }  // extern "C"

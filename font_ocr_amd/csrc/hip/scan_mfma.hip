@@ -35,7 +35,9 @@ int ensure_hit_capacity(focr_ctx *c, size_t want);
 int sort_keys_u64(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned end_bit);
 int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float *sims, unsigned long long *counter,
                      unsigned long long capacity, int rust);
-int order_sorted_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos, size_t n);
+int compact_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos,
+                       const unsigned long long *n_cand_p, size_t ub_c);
+int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c);
 
 
 // ---------------------------------------------------------------------------------------------
@@ -205,15 +207,15 @@ typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned 16-byte view (gf
 // Candidates arrive sorted by the packed key (page, y, x, t): neighbouring lanes verify the same or neighbouring
 // windows (cache-friendly), and the survivors stay in process_hits order, so no atomics: flag[i] / sim[i] are
 // written in place and order.hip compacts them and derives the per-call lists.
-__global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, unsigned long long n_cand,
+__global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long ub,
                                                      const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                      KeyFmt fmt, const uint32_t *__restrict__ order_of,
                                                      const TemplateConst *__restrict__ tc, const v4i *__restrict__ needles16,
                                                      const uint32_t *__restrict__ needle16_row, double thr_d,
                                                      float *__restrict__ sims, uint64_t *__restrict__ flags) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_cand) return;
-    if (i == n_cand) {  // sentinel so that the exclusive scan of flags also yields the total
+    if (i > ub) return;  // grid and buffers are sized for `ub` candidates (+ the sentinel at ub)
+    if (i >= min(*n_cand_p, ub)) {  // past the device-side count (and the sentinel: the exclusive scan of flags also yields the total)
         flags[i] = 0;
         return;
     }
@@ -484,6 +486,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
     size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->sub_np * 131072));
+    if (c->estimated) want_cand = std::max(want_cand, c->est_cand);
     hipDeviceProp_t prop;
     FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
 
@@ -499,6 +502,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         c->counters[3] = 0;
         c->launches_reset();
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 7 * sizeof(uint64_t), c->stream));
+        // Sizes.  Exact mode: the host reads the candidate count after the scan kernels and the hit count after the
+        // verify (two waits), so every later phase runs on exact sizes.  Estimated mode (ctx.hip: same setup as the
+        // previous scan): the counts stay on the device, grids and buffers take the previous counts + 20 % as bounds,
+        // unused candidate slots hold the largest key so that the sort leaves them at the end; nothing waits.
+        c->ub_cand = c->estimated ? std::min(c->est_cand, c->cand_capacity) : c->cand_capacity;
+        if (c->estimated) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
         size_t tiles_total = 0;
@@ -699,33 +709,28 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const SizeClass &sc = c->classes[k];
             if (!sc.tall || sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
             if ((rc = launch_scan_tall(c, k, thr_d, c->d_cand, nullptr, (unsigned long long *)c->d_counter + 1,
-                                       (unsigned long long)c->cand_capacity, 0)))
+                                       (unsigned long long)c->ub_cand, 0)))
                 return rc;
         }
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
-        unsigned long long n_cand = 0;
-        uint32_t live_counts[40] = {0};
-        FOCR_HIP(c, hipMemcpyAsync(&n_cand, (unsigned long long *)c->d_counter + 1, 8, hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipMemcpyAsync(live_counts, c->d_counter + 8, sizeof live_counts, hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipStreamSynchronize(c->stream));
-        c->counters[3] = 0;
-        for (focr_launch_info_t &li : c->launches) {  // issued MACs follow the number of live M-tiles (known only now)
-            if (strncmp(li.name, "scan_mfma", 9) == 0) {
-                li.issued_macs *= live_counts[li.n_templates >> 24];
-                li.n_templates &= 0xffffff;
+        FOCR_HIP(c, hipMemcpyAsync(c->h_live, c->d_counter + 8, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        const unsigned long long *n_cand_p = (const unsigned long long *)c->d_counter + 1;
+        size_t ub_c = c->ub_cand;
+        if (!c->estimated) {
+            unsigned long long n_cand = 0;
+            FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
+            FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            if (n_cand > c->cand_capacity) {
+                if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
+                want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;
+                continue;
             }
-            c->counters[3] += li.issued_macs;
+            ub_c = (size_t)n_cand;
         }
-        if (n_cand > c->cand_capacity) {
-            if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
-            want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;
-            continue;
-        }
-        c->n_cand = (size_t)n_cand;
         // 3. sort the candidates into emission order, verify them exactly in place, compact + cap (order.hip)
-        if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, (size_t)n_cand + 1)))) return rc;
-        uint64_t *flags = (uint64_t *)c->scan_flags.ensure(c, ((size_t)n_cand + 1) * 8);
-        uint64_t *pos = (uint64_t *)c->scan_pos.ensure(c, ((size_t)n_cand + 1) * 8);
+        if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
+        uint64_t *flags = (uint64_t *)c->scan_flags.ensure(c, (ub_c + 1) * 8);
+        uint64_t *pos = (uint64_t *)c->scan_pos.ensure(c, (ub_c + 1) * 8);
         if (!flags || !pos) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
         if (c->cand_alt_capacity < c->cand_capacity) {
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
@@ -735,22 +740,22 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (hipMalloc(&c->d_cand_alt, c->cand_capacity * 8) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
             c->cand_alt_capacity = c->cand_capacity;
         }
-        if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, (size_t)n_cand, c->fmt.bits()))) return rc;
-        hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((n_cand + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand,
+        if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, ub_c, c->fmt.bits()))) return rc;
+        hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((ub_c + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand_p, (unsigned long long)ub_c,
                            c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of,
                            c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_sims,
                            flags);
         FOCR_HIP(c, hipGetLastError());
         FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
-        if ((rc = order_sorted_candidates(c, c->d_cand, c->d_hit_sims, flags, pos, (size_t)n_cand))) return rc;
-        const unsigned long long n_hits = c->n_hits_raw;
-        FOCR_HIP(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
-        FOCR_HIP(c, hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]));
-        FOCR_HIP(c, hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[3]));
-        c->counters[0] = n_cand;
-        c->counters[1] = n_hits;
-        c->launches_collect();
-        return FOCR_OK;
+        if ((rc = compact_candidates(c, c->d_cand, c->d_hit_sims, flags, pos, n_cand_p, ub_c))) return rc;
+        size_t ub_h = std::min(ub_c, c->est_hits);
+        if (!c->estimated) {  // exact number of hits for the ordering pass
+            uint64_t hits = 0;
+            FOCR_HIP(c, hipMemcpyAsync(&hits, pos + ub_c, 8, hipMemcpyDeviceToHost, c->stream));
+            FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            ub_h = (size_t)hits;
+        }
+        return order_sorted_hits(c, c->d_hit_keys, c->d_hit_sims_alt, pos + ub_c, ub_h, n_cand_p, ub_c);
     }
     return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: candidate buffer kept overflowing");
 }

@@ -390,7 +390,7 @@ static void launch_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, con
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset),
                        reinterpret_cast<const v4i *>(basis), reinterpret_cast<const v4i *>(gbank), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
-                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->cand_capacity);
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand);
     c->launch_end();
 }
 

@@ -174,6 +174,10 @@ class Scanner:
         """PREFILTER_AUTO / PREFILTER_ONE_STAGE / PREFILTER_TWO_STAGE (focr_ctx_set_prefilter); results never change."""
         self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
 
+    def set_size_estimates(self, on):
+        """focr_ctx_set_size_estimates: repeat scans of one setup queue every phase without host waits (default on)."""
+        self._ck(self._lib.focr_ctx_set_size_estimates(self._h, int(bool(on))))
+
     def force_split(self, on):
         """Test hook (focr_debug_force_split): scan the batch in page sub-ranges as after a candidate overflow."""
         self._ck(self._lib.focr_debug_force_split(self._h, int(bool(on))))

@@ -750,3 +750,51 @@ def test_rust_scan_mode_vs_oracle(scanner, bank_x2, thr):
     if thr < 0:
         scanner.scan(thr, cap, SCAN_DIRECT)
         assert scanner.counts().sum() > counts.sum()
+
+
+@pytest.mark.parametrize("mode", MODES[1:])
+def test_size_estimates_and_redo_on_overflow(bank_x2, mode):
+    """Repeat scans of one setup run on the previous scan's counts + 20 % without host waits (focr_ctx_set_size_estimates);
+    a batch with far more hits than the previous one must overflow those bounds, be redone with exact sizes, and still give
+    the reference lists and process_hits output — also when process_hits was already queued behind the scan."""
+    bank = bank_x2.subset(list(range(33, 80)) + list(range(95 + 33, 95 + 80)))
+    dense = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 900 + p, 300, 130) for p in range(3)])
+    sparse = np.full_like(dense, 255)
+    sparse[:, 20:40, 30:120] = dense[:, 20:40, 30:120]  # a few glyphs only
+    want = {"sparse": _oracle_lists(sparse, bank, 0.7, 1024), "dense": _oracle_lists(dense, bank, 0.7, 1024)}
+    n_sparse, n_dense = (sum(len(x) for p in want[k] for x in p) for k in ("sparse", "dense"))
+    assert n_dense > 5 * n_sparse + 100_000 or n_dense > 20 * n_sparse
+    with Scanner(0) as sc:
+        sc.set_bank(bank)
+        sc.set_pages(sparse)
+
+        def check(which):
+            offsets, m = sc.matches()
+            _assert_same(_csr_to_lists(offsets, m, 3, len(bank)), want[which], which)
+
+        sc.scan(0.7, 1024, mode)       # first scan of the setup: exact sizes
+        check("sparse")
+        sc.scan(0.7, 1024, mode)       # second: estimated sizes, nothing waits until the getter
+        sc.process_hits(0.9, 5)
+        lines_a = sc.lines_flat().copy()
+        check("sparse")
+        sc.upload_pages(dense, 0)      # same geometry, ~10x the hits: the estimates are far too small
+        sc.scan(0.7, 1024, mode)
+        sc.process_hits(0.9, 5)        # queued behind the scan that will have to be redone
+        lines_b = sc.lines_flat().copy()
+        check("dense")
+        sc.scan(0.7, 1024, mode)       # estimates now come from the dense batch
+        check("dense")
+        sc.process_hits(0.9, 5)
+        assert sc.lines_flat().tobytes() == lines_b.tobytes() and len(lines_b) > len(lines_a)
+        sc.set_size_estimates(False)   # round-1 behaviour: counts read between the phases
+        sc.scan(0.7, 1024, mode)
+        check("dense")
+        sc.process_hits(0.9, 5)
+        assert sc.lines_flat().tobytes() == lines_b.tobytes()
+        sc.upload_pages(sparse, 0)
+        sc.set_size_estimates(True)
+        sc.scan(0.7, 1024, mode)       # bounds from the dense batch: plenty
+        sc.process_hits(0.9, 5)
+        check("sparse")
+        assert sc.lines_flat().tobytes() == lines_a.tobytes()
