@@ -94,6 +94,8 @@ HIP_SYMBOLS = {
     "focr_pages_upload": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "focr_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "focr_host_free": (None, [C.c_void_p]),
+    "focr_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "focr_host_unregister": (None, [C.c_void_p]),
     "focr_pages_upload_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "focr_scan": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_int]),
     "focr_get_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -121,6 +123,9 @@ HIP_SYMBOLS = {
     "focr_pipe_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_float,
                                    C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_uint64)]),
+    "focr_pipe_set_fetch": (C.c_int, [C.c_void_p, C.c_int]),
+    "focr_pipe_host_results": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "focr_get_lines_into": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "focr_pipe_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "focr_pipe_release": (C.c_int, [C.c_void_p, C.c_uint64]),
     "focr_last_launches": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -133,6 +138,9 @@ HOST_SYMBOLS = {
     "focr_bank_load": (C.c_int, [C.c_char_p, C.POINTER(BankStruct)]),
     "focr_image_load_luma8": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "focr_image_probe": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "focr_image_load_luma8_into": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                             C.c_char_p, C.c_size_t]),
     "focr_image_save_pgm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "focr_synth_page": (C.c_size_t, [C.POINTER(BankStruct), C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_size_t]),

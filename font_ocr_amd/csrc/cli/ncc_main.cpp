@@ -253,7 +253,8 @@ struct PhaseClock {  // -v: wall time of each host phase, on stderr
 int main(int argc, char **argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);  // more streams than the default 4 hardware queues must not share one
     Args args = parse_args(argc, argv);
-    PhaseClock clk{args.verbose};
+    const bool timing = args.verbose || getenv("FOCR_CLI_TIMING") != nullptr;  // phase / pipeline summary lines on stderr
+    PhaseClock clk{timing};
     int box = args.box_size == "font" ? FOCR_BOX_FONT : args.box_size == "alphabet" ? FOCR_BOX_ALPHABET : args.box_size == "char" ? FOCR_BOX_CHAR : -1;
     if (box < 0) die("called `Result::unwrap()` on an `Err` value: () (--box-size must be font, alphabet or char)");  // src/ncc.rs:559
     if (args.raw && args.img.size() != 1) die("assertion failed: args.img.len() == 1");  // src/ncc.rs:834
@@ -283,49 +284,105 @@ int main(int argc, char **argv) {
     }
     if (args.img.empty()) return 0;
 
-    // Pipeline: images are decoded by all host cores in index order, in batches of
-    // kBatch pages; the GPU context comes up meanwhile; the main thread scans batch b while batches b+1.. decode.
-    // Pages of one batch are grouped by size (one resident device batch per size).  Output is produced per page
-    // and written in page order, so the bytes on stdout are those of the reference's sorted print (src/ncc.rs:845-877).
+    // Pipeline (the reference's page parallelism, src/ncc.rs:839-847, on the GPU's terms):
+    //   1. all host cores read the image headers, then the batch plan is fixed: consecutive pages of one size, at most
+    //      kBatch per batch, each batch owning one page-aligned slab slot per page;
+    //   2. the same cores decode, in index order, straight into their page's slot (binary PGM: one fread), while the
+    //      main thread brings the HIP runtime up and page-locks the slabs (focr_host_register);
+    //   3. a decoded batch goes to the next device round-robin (every visible GPU, FOCR_CLI_DEVICES caps the count) as
+    //      ONE upload + scan + process_hits on one lane of that device's executor (focr_pipe_*: FOCR_CLI_CONTEXTS lanes
+    //      per device, default 3), so a batch's DMA and small kernels run under other batches' MFMA scans;
+    //   4. results are retired in batch order and written in page order: the bytes on stdout are those of the
+    //      reference's sorted print (src/ncc.rs:845-877) whatever the device count.
     const size_t N = args.img.size();
-    size_t kBatch = 256, kAhead = 5;  // decode-ahead in batches; must exceed the contexts in flight (<= 4)
+    size_t kBatch = 128;
     if (const char *e = getenv("FOCR_CLI_BATCH")) kBatch = std::max<size_t>(1, strtoul(e, nullptr, 10));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+
     struct Page {
-        uint8_t *px = nullptr;
-        size_t w = 0, h = 0;
+        size_t w = 0, h = 0, batch = 0, slot = 0;
         std::string err;
     };
     std::vector<Page> pages(N);
-    const size_t n_batches = (N + kBatch - 1) / kBatch;
-    std::vector<size_t> left(n_batches);
-    for (size_t b = 0; b < n_batches; b++) left[b] = std::min(kBatch, N - b * kBatch);
+    unsigned n_threads = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));  // more threads only fight over the address space
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // a container's CPU quota: threads beyond it only get throttled (measured: 4 096
+        unsigned long long quota = 0, period = 0;           // headers in 15 ms with 16 threads on a 16-CPU quota, 130 ms with 64)
+        if (fscanf(f, "%llu %llu", &quota, &period) == 2 && period) n_threads = std::min<unsigned>(n_threads, (unsigned)std::max<unsigned long long>(1, quota / period));
+        fclose(f);
+    }
+    if (const char *e = getenv("FOCR_CLI_THREADS")) n_threads = std::max(1u, (unsigned)strtoul(e, nullptr, 10));
+    n_threads = (unsigned)std::min<size_t>(n_threads, N);
+    {  // 1. headers
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_threads; t++)
+            th.emplace_back([&]() {
+                for (size_t i; (i = next.fetch_add(1)) < N;) {
+                    char e[256] = {0};
+                    if (focr_image_probe(args.img[i].c_str(), &pages[i].w, &pages[i].h, e, sizeof e) != 0) pages[i].err = e[0] ? e : "?";
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    for (size_t i = 0; i < N; i++)
+        if (!pages[i].err.empty()) die("cannot open image: " + pages[i].err);  // image::open(..).unwrap(), src/ncc.rs:575
+    struct Batch {
+        size_t p0 = 0, n = 0, w = 0, h = 0;
+    };
+    std::vector<Batch> batches;
+    size_t max_bytes = 0;
+    for (size_t i = 0; i < N; i++) {
+        if (batches.empty() || batches.back().n == kBatch || batches.back().w != pages[i].w || batches.back().h != pages[i].h)
+            batches.push_back(Batch{i, 0, pages[i].w, pages[i].h});
+        pages[i].batch = batches.size() - 1;
+        pages[i].slot = batches.back().n++;
+        max_bytes = std::max(max_bytes, batches.back().n * pages[i].w * pages[i].h);
+    }
+    const size_t n_batches = batches.size();
+    clk.lap("headers + plan");
+
+    // devices and lanes
+    size_t n_dev = 1, n_lanes = 3;
+    if (const char *e = getenv("FOCR_CLI_CONTEXTS")) n_lanes = std::min<size_t>(8, std::max<size_t>(1, strtoul(e, nullptr, 10)));
+    size_t dev_cap = ~(size_t)0;
+    if (const char *e = getenv("FOCR_CLI_DEVICES")) dev_cap = std::max<size_t>(1, strtoul(e, nullptr, 10));
+    if (args.raw) n_lanes = 1, dev_cap = 1;
+
+    // 2. slabs: enough for every lane of every device to hold one batch plus a few being decoded ahead
+    const size_t slab_bytes = (max_bytes + 4095) / 4096 * 4096;
     std::mutex mu;
     std::condition_variable cv;
-    size_t consumed = 0;  // batches the main thread has finished with (guarded by mu)
+    std::vector<size_t> left(n_batches);
+    for (size_t b = 0; b < n_batches; b++) left[b] = batches[b].n;
+    std::vector<uint8_t *> slabs;          // slab of batch b = slabs[b % slabs.size()] once batch b - slabs.size() is retired
+    size_t retired = 0;                    // batches whose results have been written (guarded by mu)
+    size_t n_slabs = 0;                    // set once the device count is known (guarded by mu; 0 = decoders wait)
     bool stop = false;
     std::atomic<size_t> next{0};
     auto decode_worker = [&]() {
         for (size_t i; (i = next.fetch_add(1)) < N;) {
-            const size_t b = i / kBatch;
+            const size_t b = pages[i].batch;
+            uint8_t *slab;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || b < consumed + kAhead; });  // bound the decoded pages held in memory
+                cv.wait(lk, [&] { return stop || (n_slabs && b < retired + n_slabs); });
                 if (stop) return;
+                slab = slabs[b % n_slabs];
             }
+            const size_t bytes = batches[b].w * batches[b].h;
+            size_t w = 0, h = 0;
             char e[256] = {0};
-            if (focr_image_load_luma8(args.img[i].c_str(), &pages[i].px, &pages[i].w, &pages[i].h, e, sizeof e) != 0)
+            if (focr_image_load_luma8_into(args.img[i].c_str(), slab + pages[i].slot * bytes, bytes, &w, &h, e, sizeof e) != 0)
                 pages[i].err = e[0] ? e : "?";
+            else if (w != pages[i].w || h != pages[i].h)
+                pages[i].err = args.img[i] + ": size changed between header and decode";
             std::lock_guard<std::mutex> lk(mu);
             if (--left[b] == 0) cv.notify_all();
         }
     };
     std::vector<std::thread> pool;
-    {
-        unsigned hw = std::min(64u, std::thread::hardware_concurrency());  // more threads only fight over the address space
-        if (const char *e = getenv("FOCR_CLI_THREADS")) hw = (unsigned)strtoul(e, nullptr, 10);
-        unsigned nt = std::max(1u, std::min<unsigned>(hw, (unsigned)std::min<size_t>(N, kBatch * kAhead)));
-        for (unsigned t = 0; t < nt; t++) pool.emplace_back(decode_worker);
-    }
+    for (unsigned t = 0; t < n_threads; t++) pool.emplace_back(decode_worker);
     auto stop_pool = [&]() {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -339,186 +396,218 @@ int main(int argc, char **argv) {
         stop_pool();
         die(msg);
     };
-
-    // FOCR_CLI_CONTEXTS=n (default 1): n device contexts take the batches alternately, each batch on its own host
-    // thread, so that one batch's upload / statistics / sort / verify overlap another's MFMA scan (the scheme of
-    // bench.py --in-flight 2).  Measured on image files it does not pay: this loop is bound by the pageable
-    // host<->device copies, not by the scan, hence the default.
-    size_t n_ctx = 1;
-    if (const char *e = getenv("FOCR_CLI_CONTEXTS")) n_ctx = std::min<size_t>(4, std::max<size_t>(1, strtoul(e, nullptr, 10)));
-    n_ctx = std::min(n_ctx, n_batches);
-    if (args.raw) n_ctx = 1;
-    std::vector<focr_ctx_t *> ctxs(n_ctx, nullptr);
-    for (size_t j = 0; j < n_ctx; j++) {
-        if (focr_ctx_create(0, &ctxs[j]) != FOCR_OK) fatal(std::string("no usable GPU: ") + focr_last_error_global());
-        if (focr_bank_upload(ctxs[j], bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
-            fatal(std::string("focr_bank_upload: ") + focr_last_error(ctxs[j]));
+    // decoders may fill the first slabs while the HIP runtime comes up: plain page-aligned memory now, page-locked below
+    {
+        const size_t first = std::min<size_t>(n_batches, 4);
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < first; k++) {
+            void *p = nullptr;
+            if (posix_memalign(&p, 4096, slab_bytes) != 0) die("out of memory");
+            slabs.push_back((uint8_t *)p);
+        }
+        n_slabs = first;
     }
+    cv.notify_all();
+
+    n_dev = std::min<size_t>({(size_t)std::max(0, focr_device_count()), dev_cap, n_batches});
+    if (n_dev == 0) fatal(std::string("no usable GPU: ") + focr_last_error_global());
+    n_lanes = std::min(n_lanes, (n_batches + n_dev - 1) / n_dev);
+    std::vector<focr_pipe_t *> pipes(n_dev, nullptr);
+    {
+        std::vector<std::thread> th;  // one thread per device: context creation and bank upload in parallel
+        std::vector<std::string> errs(n_dev);
+        for (size_t d = 0; d < n_dev; d++)
+            th.emplace_back([&, d]() {
+                if (focr_pipe_create((int)d, (unsigned)n_lanes, &pipes[d]) != FOCR_OK) errs[d] = std::string("no usable GPU: ") + focr_last_error_global();
+                else if (focr_pipe_bank_upload(pipes[d], bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
+                    errs[d] = std::string("focr_bank_upload: ") + focr_last_error_global();
+                else
+                    focr_pipe_set_fetch(pipes[d], 1);  // every lane copies its batch's counts and lines to page-locked memory itself
+            });
+        for (auto &t : th) t.join();
+        for (const std::string &e : errs)
+            if (!e.empty()) fatal(e);
+    }
+    {  // the remaining slabs, and page-lock all of them (a slab that cannot be locked still works, through a staged copy)
+        const size_t want = std::min(n_batches, n_dev * n_lanes + 4);
+        std::vector<uint8_t *> more;
+        for (size_t k = slabs.size(); k < want; k++) {
+            void *p = nullptr;
+            if (posix_memalign(&p, 4096, slab_bytes) != 0) fatal("out of memory");
+            more.push_back((uint8_t *)p);
+        }
+        // Growing the ring re-maps batch -> slab, so it may only happen while no decoded batch depends on the old
+        // mapping: batches below `first` keep their slabs because b % first == b there and b % want == b as well.
+        std::lock_guard<std::mutex> lk(mu);
+        for (uint8_t *p : more) slabs.push_back(p);
+        n_slabs = slabs.size();
+    }
+    cv.notify_all();
+    for (uint8_t *p : slabs) (void)focr_host_register(p, slab_bytes);
     // --rust: the scalar scan's arithmetic and its missing cap (src/ncc.rs:320-330, 406-483) on the exact device kernel
     const int mode = args.rust ? FOCR_SCAN_RUST : FOCR_SCAN_MFMA;
     const uint32_t cap = args.rust ? 0xffffffffu : (uint32_t)FOCR_MAX_MATCHES;
     clk.lap("ctx + bank");
 
     const size_t T = bank.n_templates;
-    struct BatchOut {
-        std::string text, err, log;
-        double ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
-    };
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    double ms_wait = 0, ms_results = 0, ms_format = 0, ms_device = 0;
+    std::string out;
+    std::vector<uint64_t> tickets(n_batches, 0);
+    std::vector<uint64_t> hits_by_letter;  // -v: hits per alphabet letter over all pages (src/ncc.rs:703-718)
+    if (args.verbose) hits_by_letter.assign(alphabet.size(), 0);
 
-    // Everything the device does for one decoded batch; runs on a worker thread, touches only its own context.
-    auto process_batch = [&](size_t b, focr_ctx_t *ctx) -> BatchOut {
-        BatchOut r;
-        const size_t p0 = b * kBatch, p1 = std::min(N, p0 + kBatch);
-#define CKB(expr)                                                        \
-    do {                                                                 \
-        if ((expr) != FOCR_OK) {                                         \
-            r.err = std::string(#expr) + ": " + focr_last_error(ctx);    \
-            return r;                                                    \
-        }                                                                \
-    } while (0)
-        std::map<std::pair<size_t, size_t>, std::vector<size_t>> groups;
-        for (size_t i = p0; i < p1; i++) {
-            if (!pages[i].err.empty()) {  // image::open(..).unwrap(), src/ncc.rs:575
-                r.err = "cannot open image: " + pages[i].err;
-                return r;
-            }
-            groups[{pages[i].w, pages[i].h}].push_back(i);
-        }
-        std::vector<std::string> page_out(p1 - p0);
-        for (auto &kv : groups) {
-            const size_t w = kv.first.first, h = kv.first.second;
-            const std::vector<size_t> &idx = kv.second;
-            auto t0 = now();
-            CKB(focr_pages_alloc(ctx, idx.size(), w, h));
-            for (size_t k = 0; k < idx.size(); k++) CKB(focr_pages_upload(ctx, k, 1, pages[idx[k]].px, 1));
-            r.ms_upload += since(t0);
-            t0 = now();
-            CKB(focr_scan(ctx, args.threshold, cap, mode));
-            r.ms_scan += since(t0);
-            t0 = now();
-            std::vector<uint32_t> counts(idx.size() * T);
-            CKB(focr_get_counts(ctx, counts.data()));
-            for (uint32_t cnt : counts)
-                if (!args.rust && cnt == FOCR_MAX_MATCHES) r.log += "WARN got >= " + std::to_string(FOCR_MAX_MATCHES) + " matches\n";  // src/ncc.rs:395-397
-            if (args.verbose) {
-                float ms[6];
-                focr_last_timings(ctx, ms);
-                char line[160];
-                snprintf(line, sizeof line, "scan of %zu page(s) %zux%zu: %.3fms on the device, hits: %zu\n", idx.size(), w, h, ms[5],
-                         focr_total_matches(ctx));
-                r.log += line;
-            }
-            if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit, in get_hits order (exactly one image: src/ncc.rs:834)
-                std::vector<uint64_t> off(idx.size() * T + 1);
-                std::vector<focr_match_t> m(focr_total_matches(ctx));
-                CKB(focr_get_matches(ctx, off.data(), m.data()));
+    // results of batch b: read from its lane's context, formatted in page order, lane and slab released
+    auto retire = [&](size_t b) {
+        const Batch &B = batches[b];
+        focr_pipe_t *pipe = pipes[b % n_dev];
+        focr_host_results_t R{};
+        auto t0 = now();
+        if (focr_pipe_host_results(pipe, tickets[b], &R) != FOCR_OK) fatal(std::string("scan: ") + focr_last_error_global());
+        const uint32_t *counts = R.counts;
+        for (size_t q = 0; q < B.n * T; q++)
+            if (!args.rust && counts[q] == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+        ms_device += R.device_ms;
+        if (args.verbose) {
+            // the reference's per-template line (src/ncc.rs:657-666); one device pass scans every template of every page of
+            // the batch, so "elapsed" is the batch's device time divided evenly over its (page, template) pairs
+            const double per_pair_ms = (double)R.device_ms / (double)(B.n * T);
+            for (size_t k = 0; k < B.n; k++) {
+                uint64_t page_hits = 0;
                 for (size_t t = 0; t < T; t++) {
                     const focr_template_t &d = bank.templates[t];
-                    for (uint64_t q = off[t]; q < off[t + 1]; q++) {
-                        float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
-                        char row[256];
-                        snprintf(row, sizeof row, "%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x,
-                                 m[q].y, d.n_w, d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(),
-                                 f32s(d.off_y).c_str());
-                        r.text += row;
-                    }
+                    const uint32_t cnt = counts[k * T + t];
+                    page_hits += cnt;
+                    hits_by_letter[t % alphabet.size()] += cnt;
+                    fprintf(stderr, "`%s` [%s, %s] needle size %ux%u hits %u elapsed %.4fms (%.4f ns/pixel, batch average)\n",
+                            utf8_encode(d.letter).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str(), d.n_w, d.n_h, cnt, per_pair_ms,
+                            per_pair_ms * 1e6 / (double)(B.w * B.h));
                 }
-                return r;
+                fprintf(stderr, "overall %.4fms\nhits: %llu\n", (double)R.device_ms / (double)B.n, (unsigned long long)page_hits);
             }
-            CKB(focr_process_hits(ctx, args.anchor_threshold, args.overlap));
-            std::vector<uint64_t> page_off(idx.size() + 1), line_off(focr_total_lines(ctx) + 1);
-            std::vector<focr_hit_t> chars(focr_total_chars(ctx));
-            CKB(focr_get_lines(ctx, page_off.data(), line_off.data(), chars.data()));
-            r.ms_post += since(t0);
-            t0 = now();
-            for (size_t k = 0; k < idx.size(); k++) {  // output, src/ncc.rs:849-877
-                std::string &s = page_out[idx[k] - p0];
-                for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++) {
-                    if (!args.csv) {
-                        const size_t nq = line_off[l + 1] - line_off[l];
-                        std::string line(4 * nq + (args.spaces ? 4096 : 0) + 1, '\0');
-                        size_t need = focr_line_text(chars.data() + line_off[l], nq, bank.advance_px, args.spaces, &line[0], line.size());
-                        if (need + 1 > line.size()) {  // a very wide gap: size exactly and redo
-                            line.assign(need + 1, '\0');
-                            need = focr_line_text(chars.data() + line_off[l], nq, bank.advance_px, args.spaces, &line[0], line.size());
-                        }
-                        line.resize(need);
-                        s += line;
-                        s += '\n';
-                        continue;
+        }
+        const uint64_t *page_off = R.page_line_off, *line_off = R.line_char_off;
+        const focr_hit_t *chars = R.chars;
+        ms_results += since(t0);
+        t0 = now();
+        for (size_t k = 0; k < B.n; k++) {  // output, src/ncc.rs:849-877
+            for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++) {
+                const size_t nq = line_off[l + 1] - line_off[l];
+                if (!args.csv) {
+                    const size_t at = out.size();
+                    out.resize(at + 4 * nq + (args.spaces ? 4096 : 0) + 1);
+                    size_t need = focr_line_text(chars + line_off[l], nq, bank.advance_px, args.spaces, &out[at], out.size() - at);
+                    if (need + 1 > out.size() - at) {  // a very wide gap: size exactly and redo
+                        out.resize(at + need + 1);
+                        need = focr_line_text(chars + line_off[l], nq, bank.advance_px, args.spaces, &out[at], out.size() - at);
                     }
-                    for (uint64_t q = line_off[l]; q < line_off[l + 1]; q++) {
-                        const focr_hit_t &c = chars[q];
-                        float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
-                        char row[160];
-                        snprintf(row, sizeof row, "%zu,%u,%s,%s,%u,%u,%u,%u\n", idx[k], c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x,
-                                 c.y, c.w, c.h);
-                        s += row;
-                    }
+                    out.resize(at + need);
+                    out += '\n';
+                    continue;
+                }
+                for (uint64_t q = line_off[l]; q < line_off[l + 1]; q++) {
+                    const focr_hit_t &c = chars[q];
+                    float cx = (float)c.x + (float)c.w * 0.5f, cy = (float)c.y + (float)c.h * 0.5f;
+                    char row[160];
+                    snprintf(row, sizeof row, "%zu,%u,%s,%s,%u,%u,%u,%u\n", B.p0 + k, c.letter, f32s(cx).c_str(), f32s(cy).c_str(), c.x, c.y, c.w,
+                             c.h);
+                    out += row;
                 }
             }
-            r.ms_format += since(t0);
         }
-#undef CKB
-        for (size_t i = p0; i < p1; i++) {
-            r.text += page_out[i - p0];
-            free(pages[i].px);
-            pages[i].px = nullptr;
-        }
-        return r;
-    };
-
-    double ms_wait = 0, ms_upload = 0, ms_scan = 0, ms_post = 0, ms_format = 0;
-    std::deque<std::future<BatchOut>> inflight;  // oldest first: results are written in batch order
-    std::string out;
-    size_t retired = 0;
-    auto retire = [&]() {
-        BatchOut r = inflight.front().get();
-        inflight.pop_front();
-        fputs(r.log.c_str(), stderr);
-        if (!r.err.empty()) {
-            for (auto &f : inflight) f.wait();
-            fatal(r.err);
-        }
-        ms_upload += r.ms_upload, ms_scan += r.ms_scan, ms_post += r.ms_post, ms_format += r.ms_format;
-        out += r.text;
-        retired++;
-        if (out.size() > (1u << 20) || retired == n_batches) {
+        if (focr_pipe_release(pipe, tickets[b]) != FOCR_OK) fatal("focr_pipe_release failed");  // the lane's result buffers are free again
+        if (out.size() > (1u << 20) || b + 1 == n_batches) {
             fwrite(out.data(), 1, out.size(), stdout);
             out.clear();
         }
+        ms_format += since(t0);
         {
             std::lock_guard<std::mutex> lk(mu);
-            consumed = retired;
+            retired = b + 1;  // its slab may be refilled
         }
         cv.notify_all();
     };
+
+    if (args.raw) {  // src/ncc.rs:683-698: every pre-NMS hit of the one image, in get_hits order, then exit without process_hits
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return left[0] == 0; });
+        }
+        if (!pages[0].err.empty()) fatal("cannot open image: " + pages[0].err);
+        uint64_t ticket = 0;
+        focr_ctx_t *ctx = nullptr;
+        if (focr_pipe_submit(pipes[0], slabs[0], 0, 1, batches[0].w, batches[0].h, 1, args.threshold, cap, mode, 0, args.anchor_threshold, args.overlap, nullptr,
+                             0, &ticket) != FOCR_OK ||
+            focr_pipe_wait(pipes[0], ticket, &ctx) != FOCR_OK)
+            fatal(std::string("scan: ") + (ctx ? focr_last_error(ctx) : focr_last_error_global()));
+        std::vector<uint32_t> counts(T);
+        CK(ctx, focr_get_counts(ctx, counts.data()));
+        for (uint32_t cnt : counts)
+            if (!args.rust && cnt == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
+        std::vector<uint64_t> off(T + 1);
+        std::vector<focr_match_t> m(focr_total_matches(ctx));
+        CK(ctx, focr_get_matches(ctx, off.data(), m.data()));
+        for (size_t t = 0; t < T; t++) {
+            const focr_template_t &d = bank.templates[t];
+            for (uint64_t q = off[t]; q < off[t + 1]; q++) {
+                float cx = (float)m[q].x + (float)d.n_w * 0.5f, cy = (float)m[q].y + (float)d.n_h * 0.5f;
+                char row[256];
+                snprintf(row, sizeof row, "%u,%s,%s,%u,%u,%u,%u,%s,%s,%s,%s\n", d.letter, f32s(cx).c_str(), f32s(cy).c_str(), m[q].x, m[q].y, d.n_w,
+                         d.n_h, f32s(d.bearing_x).c_str(), f32s(d.corrected_off_y).c_str(), f32s(d.off_x).c_str(), f32s(d.off_y).c_str());
+                out += row;
+            }
+        }
+        fwrite(out.data(), 1, out.size(), stdout);
+        focr_pipe_release(pipes[0], ticket);
+        stop_pool();
+        fflush(stdout);
+        fflush(stderr);
+        _exit(0);
+    }
+
+    // 3 + 4. submit in batch order (device b % n_dev, lanes round-robin inside the executor), retire in batch order
+    const size_t max_inflight = n_dev * n_lanes;
+    size_t next_retire = 0;
     for (size_t b = 0; b < n_batches; b++) {
-        if (inflight.size() == n_ctx) retire();  // context b % n_ctx is the one that ran batch b - n_ctx
+        while (b - next_retire >= max_inflight) retire(next_retire++);  // the lane batch b maps to still holds batch b - max_inflight
         auto t0 = now();
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return left[b] == 0; });  // b <= retired + n_ctx - 1 < consumed + kAhead: decoders may reach it
+            cv.wait(lk, [&] { return left[b] == 0; });
         }
         ms_wait += since(t0);
-        inflight.push_back(std::async(std::launch::async, process_batch, b, ctxs[b % n_ctx]));
+        for (size_t i = batches[b].p0; i < batches[b].p0 + batches[b].n; i++)
+            if (!pages[i].err.empty()) fatal("cannot open image: " + pages[i].err);  // image::open(..).unwrap(), src/ncc.rs:575
+        uint8_t *slab;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            slab = slabs[b % n_slabs];
+        }
+        if (focr_pipe_submit(pipes[b % n_dev], slab, 0, batches[b].n, batches[b].w, batches[b].h, 1, args.threshold, cap, mode, 1, args.anchor_threshold,
+                             args.overlap, nullptr, 0, &tickets[b]) != FOCR_OK)
+            fatal(std::string("focr_pipe_submit: ") + focr_last_error_global());
     }
-    while (!inflight.empty()) retire();
+    while (next_retire < n_batches) retire(next_retire++);
     stop_pool();
-    if (args.verbose)
-        fprintf(stderr, "pipeline: %zu batch(es) of <= %zu pages on %zu context(s); main thread waited %.2f ms for decode; per-batch sums: "
-                        "upload %.2f ms, scan %.2f ms, counts+process_hits+fetch %.2f ms, format %.2f ms\n",
-                n_batches, kBatch, n_ctx, ms_wait, ms_upload, ms_scan, ms_post, ms_format);
+    if (args.verbose) {
+        std::vector<std::pair<uint64_t, uint32_t>> by;  // src/ncc.rs:711-718: (count, char) ascending, zero counts skipped
+        for (size_t a = 0; a < alphabet.size(); a++)
+            if (hits_by_letter[a]) by.push_back({hits_by_letter[a], alphabet[a]});
+        std::sort(by.begin(), by.end());
+        for (auto &kv : by) fprintf(stderr, "`%s` %llu\n", utf8_encode(kv.second).c_str(), (unsigned long long)kv.first);
+    }
+    if (timing) {
+        fprintf(stderr, "pipeline: %zu batch(es) of <= %zu pages on %zu device(s) x %zu lane(s); main thread waited %.2f ms for decode; sums: device %.2f ms, "
+                        "results (wait + counts + lines) %.2f ms, format %.2f ms\n",
+                n_batches, kBatch, n_dev, n_lanes, ms_wait, ms_device, ms_results, ms_format);
+    }
     clk.lap("pages");
     fflush(stdout);
-    for (focr_ctx_t *c : ctxs) focr_ctx_destroy(c);
+    for (focr_pipe_t *p : pipes) focr_pipe_destroy(p);
     focr_bank_free(&bank);
     clk.lap("teardown");
-    if (args.verbose)
+    if (timing)
         fprintf(stderr, "total since main() %8.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clk.t0).count());
-    // Everything is flushed and the context is gone: leave without the HIP runtime's exit handlers (~170 ms).
+    // Everything is flushed and the contexts are gone: leave without the HIP runtime's exit handlers (~170 ms).
     fflush(stdout);
     fflush(stderr);
     _exit(0);

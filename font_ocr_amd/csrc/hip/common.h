@@ -104,6 +104,8 @@ struct focr_ctx {
     std::vector<size_t> direct_bank_off;        // dword offset per class
     int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
     int8_t *d_lr_basis = nullptr;               // two-stage prefilter: int8 basis rows (per-lane MFMA layout), all super-classes
+    std::vector<uint8_t> h_dense;               // class-ordered dense needles (host copy for the lazily built two-stage data)
+    bool lr_built = false;
     uint16_t *d_lr_g = nullptr;                 // two-stage prefilter: bf16 stage-2 operand, 1 KiB per N-tile
     // ---- result sizes (ctx.hip: finish_results) ----
     // Every phase after the scan kernel takes its element count from device memory; the host only supplies upper bounds for

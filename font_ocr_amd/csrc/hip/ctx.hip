@@ -495,6 +495,17 @@ void focr_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+int focr_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(nullptr, FOCR_ERR_INVALID, "focr_host_register: bad arguments");
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(nullptr, FOCR_ERR_NO_DEVICE, std::string("focr_host_register: ") + hipGetErrorString(e));
+    return FOCR_OK;
+}
+
+void focr_host_unregister(void *p) {
+    if (p) (void)hipHostUnregister(p);
+}
+
 int focr_pages_upload_device(focr_ctx_t *c, size_t first, size_t count, const void *d_luma, int invert) {
     if (!c || !d_luma) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload_device: bad arguments");
     if (!c->d_pages) return fail(c, FOCR_ERR_STATE, "focr_pages_upload_device: call focr_pages_alloc first");

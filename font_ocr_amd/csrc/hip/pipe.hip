@@ -26,9 +26,32 @@ struct PipeJob {
     size_t chars_cap = 0;       // its size in bytes
 };
 
+struct PinBuf {  // grow-only page-locked host buffer
+    void *p = nullptr;
+    size_t bytes = 0;
+    void *ensure(size_t want) {
+        if (want <= bytes && p) return p;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t grow = want + want / 4 + 4096;
+        if (hipHostMalloc(&p, grow, hipHostMallocDefault) != hipSuccess) return p = nullptr;
+        bytes = grow;
+        return p;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 struct PipeLane {
     enum State { IDLE, QUEUED, RUNNING, DONE };
     focr_ctx *ctx = nullptr;
+    // focr_pipe_set_fetch: the batch's results copied to page-locked host memory by the lane itself
+    PinBuf h_counts, h_page_off, h_line_off, h_chars;
+    focr_host_results_t res{};
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -42,6 +65,7 @@ struct PipeLane {
 }  // namespace focr
 
 struct focr_pipe {
+    bool fetch = false;
     std::vector<focr::PipeLane *> lanes;
     std::mutex mu;  // guards next_ticket
     uint64_t next_ticket = 1;
@@ -49,7 +73,7 @@ struct focr_pipe {
 
 namespace focr {
 
-static void lane_main(PipeLane *L) {
+static void lane_main(PipeLane *L, const focr_pipe *P) {
     for (;;) {
         PipeJob job;
         {
@@ -79,6 +103,29 @@ static void lane_main(PipeLane *L) {
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: copy-out failed: ") + hipGetErrorString(e));
             }
+        }
+        if (rc == FOCR_OK && P->fetch) {  // results to page-locked host memory here, on the lane's thread and stream
+            focr_host_results_t &R = L->res;
+            R = focr_host_results_t{};
+            R.n_pages = c->n_pages;
+            R.n_templates = c->n_templates;
+            R.n_matches = focr_total_matches(c);
+            R.n_lines = job.post ? focr_total_lines(c) : 0;
+            R.n_chars = job.post ? focr_total_chars(c) : 0;
+            float ms[6] = {0};
+            focr_last_timings(c, ms);
+            R.device_ms = ms[5] + ms[4];
+            uint32_t *hc = (uint32_t *)L->h_counts.ensure(R.n_pages * R.n_templates * 4 + 16);
+            uint64_t *hp = (uint64_t *)L->h_page_off.ensure((R.n_pages + 1) * 8);
+            uint64_t *hl = (uint64_t *)L->h_line_off.ensure((R.n_lines + 1) * 8);
+            focr_hit_t *hh = (focr_hit_t *)L->h_chars.ensure((R.n_chars + 1) * sizeof(focr_hit_t));
+            if (!hc || !hp || !hl || !hh) rc = fail(c, FOCR_ERR_NOMEM, "focr_pipe: page-locked result buffers: hipHostMalloc failed");
+            if (rc == FOCR_OK) rc = focr_get_counts(c, hc);
+            if (rc == FOCR_OK && job.post) rc = focr_get_lines_into(c, hp, hl, hh);
+            R.counts = hc;
+            R.page_line_off = job.post ? hp : nullptr;
+            R.line_char_off = job.post ? hl : nullptr;
+            R.chars = job.post ? hh : nullptr;
         }
         {
             std::lock_guard<std::mutex> lk(L->mu);
@@ -111,7 +158,7 @@ int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
         // several batches in flight: leave one CU of every shader engine (an eighth of the chip) to the small kernels
         if (n_contexts > 1 && hipGetDeviceProperties(&prop, device) == hipSuccess)
             focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 8));
-        L->worker = std::thread(lane_main, L);
+        L->worker = std::thread(lane_main, L, p);
         p->lanes.push_back(L);
     }
     *out = p;
@@ -128,6 +175,8 @@ void focr_pipe_destroy(focr_pipe_t *p) {
         }
         L->cv.notify_all();
         if (L->worker.joinable()) L->worker.join();
+        (void)hipSetDevice(L->ctx->device);
+        for (PinBuf *b : {&L->h_counts, &L->h_page_off, &L->h_line_off, &L->h_chars}) b->release();
         focr_ctx_destroy(L->ctx);
         delete L;
     }
@@ -186,6 +235,24 @@ int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, siz
     }
     L->cv.notify_all();
     *ticket = t;
+    return FOCR_OK;
+}
+
+int focr_pipe_set_fetch(focr_pipe_t *p, int on) {
+    if (!p) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_set_fetch: null pipe");
+    p->fetch = on != 0;  // read by the lanes when a batch completes: set it before submitting
+    return FOCR_OK;
+}
+
+int focr_pipe_host_results(focr_pipe_t *p, uint64_t ticket, focr_host_results_t *out) {
+    if (!p || !ticket || !out) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_host_results: bad arguments");
+    PipeLane *L = p->lanes[(ticket - 1) % p->lanes.size()];
+    std::unique_lock<std::mutex> lk(L->mu);
+    if (L->ticket != ticket || L->state == PipeLane::IDLE) return fail(L->ctx, FOCR_ERR_STATE, "focr_pipe_host_results: ticket is not outstanding");
+    L->cv.wait(lk, [&] { return L->state == PipeLane::DONE; });
+    if (L->rc != FOCR_OK) return L->rc;
+    if (!p->fetch) return fail(L->ctx, FOCR_ERR_STATE, "focr_pipe_host_results: call focr_pipe_set_fetch first");
+    *out = L->res;
     return FOCR_OK;
 }
 

@@ -252,6 +252,25 @@ int focr_get_lines(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *line_ch
     return FOCR_OK;
 }
 
+// Same as focr_get_lines but straight from the device into the caller's buffers (page-locked ones make it a plain DMA)
+int focr_get_lines_into(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *line_char_offsets, focr_hit_t *chars) {
+    if (!c || !page_line_offsets || !line_char_offsets || !chars) return FOCR_ERR_INVALID;
+    if (!c->processed) return fail(c, FOCR_ERR_STATE, "focr_get_lines_into: call focr_process_hits first");
+    int rc = finish_results(c);
+    if (rc) return rc;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    if (c->n_matches && (c->n_lines || c->n_chars)) {
+        if (c->n_lines) FOCR_HIP(c, hipMemcpyAsync(line_char_offsets, c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipMemcpyAsync(page_line_offsets, c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        if (c->n_chars) FOCR_HIP(c, hipMemcpyAsync(chars, c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    } else {
+        for (size_t p = 0; p <= c->n_pages; p++) page_line_offsets[p] = 0;
+    }
+    line_char_offsets[c->n_lines] = c->n_chars;
+    return FOCR_OK;
+}
+
 const focr_hit_t *focr_lines_device_chars(focr_ctx_t *c) {
     return (c && c->processed && finish_results(c) == FOCR_OK && c->n_chars) ? (const focr_hit_t *)c->post_chars.p : nullptr;
 }

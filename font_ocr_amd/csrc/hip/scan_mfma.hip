@@ -387,15 +387,9 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     }
     FOCR_HIP(c, hipMalloc((void **)&c->d_qbank, qbank.size() ? qbank.size() : 16));
     FOCR_HIP(c, hipMemcpy(c->d_qbank, qbank.data(), qbank.size(), hipMemcpyHostToDevice));
-    {  // two-stage prefilter data (lowrank.hip), per super-class that qualifies
-        std::vector<int8_t> basis;
-        std::vector<uint16_t> gb;
-        for (SuperClass &su : c->supers) build_lowrank(c, su, dense, basis, gb);
-        FOCR_HIP(c, hipMalloc((void **)&c->d_lr_basis, basis.size() ? basis.size() : 16));
-        FOCR_HIP(c, hipMemcpy(c->d_lr_basis, basis.data(), basis.size(), hipMemcpyHostToDevice));
-        FOCR_HIP(c, hipMalloc((void **)&c->d_lr_g, gb.size() ? gb.size() * 2 : 16));
-        FOCR_HIP(c, hipMemcpy(c->d_lr_g, gb.data(), gb.size() * 2, hipMemcpyHostToDevice));
-    }
+    // the two-stage prefilter's data (lowrank.hip) is built on first use: ensure_lowrank()
+    c->h_dense.assign(dense, dense + (c->h_needle_off.empty() ? 0 : c->h_needle_off.back() + c->h_tconst.back().n_w * c->h_tconst.back().n_h));
+    c->lr_built = false;
     FOCR_HIP(c, hipMalloc((void **)&c->d_tglobal, tglobal.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_tglobal, tglobal.data(), tglobal.size() * 4, hipMemcpyHostToDevice));
     // verify operand: every template as n_h rows of 16 bytes (zero padded), class-ordered
@@ -415,6 +409,26 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     FOCR_HIP(c, hipMemcpy(c->d_needle16_row, n16_row.data(), n16_row.size() * 4, hipMemcpyHostToDevice));
     FOCR_HIP(c, hipMalloc((void **)&c->d_order_of, order_of.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_order_of, order_of.data(), order_of.size() * 4, hipMemcpyHostToDevice));
+    return FOCR_OK;
+}
+
+// Two-stage prefilter data (lowrank.hip), per super-class that qualifies; built when FOCR_PREFILTER_TWO_STAGE first scans
+// (tens of ms of host work per bank that the default path should not pay at every bank upload).
+static int ensure_lowrank(focr_ctx *c) {
+    if (c->lr_built) return FOCR_OK;
+    std::vector<int8_t> basis;
+    std::vector<uint16_t> gb;
+    for (SuperClass &su : c->supers) build_lowrank(c, su, c->h_dense.data(), basis, gb);
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_lr_basis) (void)hipFree(c->d_lr_basis);
+    if (c->d_lr_g) (void)hipFree(c->d_lr_g);
+    c->d_lr_basis = nullptr;
+    c->d_lr_g = nullptr;
+    FOCR_HIP(c, hipMalloc((void **)&c->d_lr_basis, basis.size() ? basis.size() : 16));
+    FOCR_HIP(c, hipMemcpy(c->d_lr_basis, basis.data(), basis.size(), hipMemcpyHostToDevice));
+    FOCR_HIP(c, hipMalloc((void **)&c->d_lr_g, gb.size() ? gb.size() * 2 : 16));
+    FOCR_HIP(c, hipMemcpy(c->d_lr_g, gb.data(), gb.size() * 2, hipMemcpyHostToDevice));
+    c->lr_built = true;
     return FOCR_OK;
 }
 
@@ -485,6 +499,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     }
     int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
+    if (c->prefilter == FOCR_PREFILTER_TWO_STAGE && (rc = ensure_lowrank(c))) return rc;
     size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->sub_np * 131072));
     if (c->estimated) want_cand = std::max(want_cand, c->est_cand);
     hipDeviceProp_t prop;
@@ -510,6 +525,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         c->ub_cand = c->estimated ? std::min(c->est_cand, c->cand_capacity) : c->cand_capacity;
         if (c->estimated) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
+        // `sim > +inf` is never true (NaN thresholds arrive here as +inf, focr_scan): no statistics, no scan, zero candidates
+        // (kappa would be inf - inf = NaN and every window of every live tile a candidate for verify to reject)
+        const bool nothing = !(thr_d < (double)INFINITY);
+        if (nothing) FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        if (!nothing) {
         // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
         size_t tiles_total = 0;
         for (SuperClass &su : c->supers) {
@@ -712,6 +732,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                                        (unsigned long long)c->ub_cand, 0)))
                 return rc;
         }
+        }  // !nothing
         FOCR_HIP(c, hipEventRecord(c->ev[2], c->stream));
         FOCR_HIP(c, hipMemcpyAsync(c->h_live, c->d_counter + 8, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         const unsigned long long *n_cand_p = (const unsigned long long *)c->d_counter + 1;

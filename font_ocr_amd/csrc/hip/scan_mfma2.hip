@@ -199,8 +199,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 // window: one f32 norm per size class and M-tile stays in a register for the whole item (stats_lr_kernel's planar
 // norms, scan_mfma3.hip) and the int32 threshold -(floor(kq * norm) - 2) is formed from it once per item — no per-class
 // int32 table, no reload of C-in rows in the middle of the N-tile loop when the size class changes.
+#ifndef FOCR_V2S_NW
+#define FOCR_V2S_NW 16  // waves per workgroup (one workgroup per CU); experiment builds: make hip EXTRA=-DFOCR_V2S_NW=12
+#endif
 template <int KSTEPS, int RPG, int MT, int NW, int NV>
-__global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2s_kernel(
+__global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const Mfma3Args P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2s_kernel(
 
 template <int KSTEPS, int RPG, int NV>
 static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
-    constexpr int MT = 4, NW = 16;
+    constexpr int MT = 4, NW = FOCR_V2S_NW;
     const uint32_t n_tiles16 = L.n_tiles16;
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
     const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;

@@ -344,6 +344,66 @@ int focr_image_load_luma8(const char *path, uint8_t **px, size_t *w, size_t *h, 
     return fail(err, errlen, "unsupported image format (pnm and png only, Cargo.toml:10)");
 }
 
+// Size of an image from the first bytes of its file (PNM header / PNG IHDR); 0 on success.
+int focr_image_probe(const char *path, size_t *w, size_t *h, char *err, size_t errlen) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(err, errlen, std::string("cannot read ") + path);
+    uint8_t hd[512];
+    const size_t n = fread(hd, 1, sizeof hd, f);
+    fclose(f);
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (n >= 24 && !memcmp(hd, png_sig, 8)) {  // IHDR is the first chunk: width, height big-endian at 16, 20
+        *w = ((size_t)hd[16] << 24) | ((size_t)hd[17] << 16) | ((size_t)hd[18] << 8) | hd[19];
+        *h = ((size_t)hd[20] << 24) | ((size_t)hd[21] << 16) | ((size_t)hd[22] << 8) | hd[23];
+        return (*w && *h) ? 0 : fail(err, errlen, "png: bad header");
+    }
+    if (n >= 3 && hd[0] == 'P' && hd[1] >= '1' && hd[1] <= '6') {
+        PnmTok t{hd + 2, hd + n};
+        uint32_t W, H;
+        if (!t.next_uint(&W) || !t.next_uint(&H) || !W || !H) return fail(err, errlen, "pnm: bad header");
+        *w = W;
+        *h = H;
+        return 0;
+    }
+    return fail(err, errlen, "unsupported image format (pnm and png only, Cargo.toml:10)");
+}
+
+// Decode straight into caller memory (e.g. a page-locked batch slab): binary 8-bit PGM is one fread into dst, every
+// other format goes through the general decoder and one copy.  1 if the image does not fit `cap` bytes or cannot be read.
+int focr_image_load_luma8_into(const char *path, uint8_t *dst, size_t cap, size_t *w, size_t *h, char *err, size_t errlen) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(err, errlen, std::string("cannot read ") + path);
+    uint8_t hd[512];
+    const size_t n = fread(hd, 1, sizeof hd, f);
+    if (n >= 3 && hd[0] == 'P' && hd[1] == '5') {
+        PnmTok t{hd + 2, hd + n};
+        uint32_t W, H, maxv;
+        if (t.next_uint(&W) && t.next_uint(&H) && t.next_uint(&maxv) && W && H && maxv == 255 && t.p < t.e) {
+            const size_t hdr = (size_t)(t.p + 1 - hd), npx = (size_t)W * H;  // a single whitespace byte ends the header
+            if (npx > cap) {
+                fclose(f);
+                return fail(err, errlen, "image larger than its slot");
+            }
+            const size_t have = std::min(npx, n - std::min(n, hdr));
+            memcpy(dst, hd + hdr, have);
+            const size_t got = have + (npx > have ? fread(dst + have, 1, npx - have, f) : 0);
+            fclose(f);
+            if (got != npx) return fail(err, errlen, "pnm: truncated");
+            *w = W;
+            *h = H;
+            return 0;
+        }
+    }
+    fclose(f);
+    uint8_t *px = nullptr;
+    if (int rc = focr_image_load_luma8(path, &px, w, h, err, errlen)) return rc;
+    int rc = 0;
+    if (*w * *h > cap) rc = fail(err, errlen, "image larger than its slot");
+    else memcpy(dst, px, *w * *h);
+    free(px);
+    return rc;
+}
+
 size_t focr_line_text(const focr_hit_t *chars, size_t n, float advance_px, int spaces, char *out, size_t cap) {
     size_t need = 0;
     auto put = [&](char ch) {

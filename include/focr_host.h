@@ -51,6 +51,12 @@ int focr_bank_load(const char *path, focr_bank_t *out);
  * non-interlaced/interlaced 8/16-bit PNG.  *px is malloc'ed. */
 int focr_image_load_luma8(const char *path, uint8_t **px, size_t *w, size_t *h, char *err,
                           size_t errlen);
+/* Width and height from the file's header alone (no decode). */
+int focr_image_probe(const char *path, size_t *w, size_t *h, char *err, size_t errlen);
+/* Decode into caller memory of `cap` bytes (e.g. one slot of a page-locked batch slab, focr_host_register): binary
+ * 8-bit PGM is read in place, other formats take one extra copy.  Non-zero if it does not fit or cannot be read. */
+int focr_image_load_luma8_into(const char *path, uint8_t *dst, size_t cap, size_t *w, size_t *h, char *err,
+                               size_t errlen);
 int focr_image_save_pgm(const char *path, const uint8_t *px, size_t w, size_t h);
 
 /* Text of one output line as `ncc` prints it (src/ncc.rs:869-876): the letters

@@ -152,6 +152,10 @@ int focr_pages_upload(focr_ctx_t *ctx, size_t first, size_t count, const uint8_t
  * the context's next synchronising call returns (focr_sync, focr_scan). */
 int focr_host_alloc(size_t bytes, void **out);
 void focr_host_free(void *p);
+/* Page-lock memory the caller already owns (page-aligned start; e.g. slabs that image decoders began to fill before
+ * the HIP runtime was up), with the same effect on focr_pages_upload as focr_host_alloc memory. */
+int focr_host_register(void *p, size_t bytes);
+void focr_host_unregister(void *p);
 /* Same, from a device pointer (pages already in HBM, e.g. a torch tensor). */
 int focr_pages_upload_device(focr_ctx_t *ctx, size_t first, size_t count, const void *d_luma,
                              int invert);
@@ -182,6 +186,10 @@ size_t focr_total_lines(focr_ctx_t *ctx);
  * line_char_offsets: [total_lines+1] index into chars; chars: [total_chars]. */
 int focr_get_lines(focr_ctx_t *ctx, uint64_t *page_line_offsets, uint64_t *line_char_offsets,
                    focr_hit_t *chars);
+/* focr_get_lines without the intermediate host copy: device -> the caller's buffers ([n_pages+1], [total_lines+1],
+ * [total_chars] entries; all three required). */
+int focr_get_lines_into(focr_ctx_t *ctx, uint64_t *page_line_offsets, uint64_t *line_char_offsets,
+                        focr_hit_t *chars);
 /* Device pointer to the focr_total_chars() post-processed characters (page, line, x order) of the
  * last focr_process_hits, valid until the next scan/process call; NULL if there are none.  For
  * device-side consumers (e.g. the RCCL gather of match lists across GPUs). */
@@ -266,6 +274,20 @@ int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, 
                      size_t r_h, int invert, float threshold, uint32_t cap, int mode, int process_hits,
                      float anchor_threshold, int32_t overlap, void *chars_out, size_t chars_out_bytes,
                      uint64_t *ticket);
+/* Results on the host without touching the context from the consumer's thread: with fetch on, every lane copies its
+ * batch's per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory
+ * of its own before the batch completes; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out
+ * pointers that stay valid until focr_pipe_release.  Set fetch before the first submit. */
+typedef struct focr_host_results {
+    const uint32_t *counts;        /* [n_pages][n_templates] */
+    const uint64_t *page_line_off; /* [n_pages + 1]; NULL without process_hits */
+    const uint64_t *line_char_off; /* [n_lines + 1] */
+    const focr_hit_t *chars;       /* [n_chars] */
+    size_t n_pages, n_templates, n_matches, n_lines, n_chars;
+    float device_ms;               /* device time of the batch's scan + process_hits */
+} focr_host_results_t;
+int focr_pipe_set_fetch(focr_pipe_t *pipe, int on);
+int focr_pipe_host_results(focr_pipe_t *pipe, uint64_t ticket, focr_host_results_t *out);
 /* Blocks until the batch is done; returns its status and the context that
  * holds its results (all getters of this header apply). */
 int focr_pipe_wait(focr_pipe_t *pipe, uint64_t ticket, focr_ctx_t **ctx);

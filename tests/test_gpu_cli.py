@@ -84,8 +84,10 @@ def test_cli_batched_pipeline_is_order_preserving(tmp_path):
         save_pgm(paths[-1], pg)
     cmd = [NCC, "-f", FONT, "-t", "13", "-a", alphabet, "--csv", "-i"] + paths
     outs = []
-    for batch, contexts in (("256", "1"), ("1", "1"), ("2", "1"), ("4", "1"), ("2", "2"), ("1", "3")):
-        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH=batch, FOCR_CLI_CONTEXTS=contexts))
+    for batch, contexts, devices in (("256", "1", "1"), ("1", "1", "1"), ("2", "1", "99"), ("4", "1", "1"), ("2", "2", "99"), ("1", "3", "1"), ("3", "3", "99")):
+        # FOCR_CLI_DEVICES caps the GPUs the batches are dealt over (99 = every visible one): same bytes on stdout
+        r = subprocess.run(cmd, capture_output=True, text=True,
+                           env=dict(os.environ, FOCR_CLI_BATCH=batch, FOCR_CLI_CONTEXTS=contexts, FOCR_CLI_DEVICES=devices))
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout)
     assert len(outs[0].splitlines()) > 200
@@ -94,6 +96,11 @@ def test_cli_batched_pipeline_is_order_preserving(tmp_path):
     assert pages_seen == sorted(pages_seen) and set(pages_seen) == set(range(9))
     r = subprocess.run(cmd + [str(tmp_path / "missing.pgm")], capture_output=True, text=True, env=dict(os.environ, FOCR_CLI_BATCH="2"))
     assert r.returncode == 101 and "cannot open image" in r.stderr
+    # -v: the reference's per-template diagnostics on stderr (src/ncc.rs:657-666, 703-718); stdout is unchanged
+    r = subprocess.run(cmd[:-len(paths)] + paths[:2] + ["-v"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "".join(l + "\n" for l in outs[0].splitlines() if int(l.split(",")[0]) < 2)
+    assert r.stderr.count("needle size") == 2 * len(alphabet) and "hits: " in r.stderr and "overall " in r.stderr
 
 
 @pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")

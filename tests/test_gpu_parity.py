@@ -434,6 +434,8 @@ def test_extreme_thresholds(scanner, bank_x2, mode):
     for thr in (float("nan"), float("inf"), 2.0):
         scanner.scan(thr, 1024, mode)
         assert scanner.total_matches() == 0
+        if thr != 2.0 and mode != SCAN_DIRECT:  # the no-match threshold does no work at all: nothing reaches verify
+            assert scanner.counters()["candidates"] == 0 and scanner.launches() == []
         scanner.process_hits(0.95, 5)
         assert scanner.lines() == [[]]
     scanner.scan(float("-inf"), 64, mode)
