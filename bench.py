@@ -32,15 +32,33 @@ R_W, R_H = 608, 720
 PEAK_I8_MFMA_TOPS = 5000.0  # dense i8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
 
 
-def traffic_of(kernel_name):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md); None if the
-    file is absent or was taken for another kernel."""
+def traffic_of(kernel_name, workload):
+    """HBM-side bytes per launch of the dominant kernel, taken from committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) — only when a profile exists for exactly this kernel and
+    this workload (pages per launch, geometry, templates); otherwise None: a live run cannot read PMC counters, and a
+    number measured for another kernel or workload would be stale.  Returns (bytes, source file) or (None, None)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") == kernel_name and all(t.get("workload_key", {}).get(k) == v for k, v in workload.items()):
+            return t.get("traffic_bytes"), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def effective_cpus():
+    """CPUs this process can really use: the affinity mask, capped by the container's CFS quota (cgroup v2 cpu.max)."""
+    n = len(os.sched_getaffinity(0))
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        return t["traffic_bytes"] if t.get("kernel") == kernel_name else None
-    except (OSError, ValueError, KeyError):
-        return None
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def main():
@@ -53,15 +71,19 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pages-per-gpu", type=int, default=128)
-    ap.add_argument("--config", choices=["c2", "c3"], default="c2",
-                    help="c2 = BASELINE configs[1] (608x720, 380 templates; the headline workload); c3 = configs[2] geometry "
-                         "(1200x1600 pages, --x-bits 2 --y-bits 2 = 1520 templates)")
+    ap.add_argument("--config", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2 = BASELINE configs[1] (608x720, 380 templates; the headline workload, weak scaling); c3 = configs[2] geometry "
+                         "(1200x1600 pages, --x-bits 2 --y-bits 2 = 1520 templates); c4 = configs[3]: 8192 pages of 608x720 in all, "
+                         "sharded over the ranks in contiguous blocks (strong scaling): one step = every rank scans its 8192 / N pages "
+                         "once, as batches of --pages-per-gpu pages taken from its HBM-resident shard")
+    ap.add_argument("--c4-pages", type=int, default=8192, help="total pages of --config c4 (BASELINE configs[3]: 8192)")
     ap.add_argument("--mode", choices=["mfma", "direct"], default="mfma")
     ap.add_argument("--threshold", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pages", type=int, default=0, help="0 = 4 pages per host thread")
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
     ap.add_argument("--with-upload", action="store_true", help="also time steps that start from host pages (PCIe-inclusive rate, reported as e2e_*)")
+    ap.add_argument("--settle-s", type=float, default=0.4, help="untimed extra warm-up (seconds of steps) before the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     ap.add_argument("--scan-cus", type=int, default=-1,
                     help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
@@ -121,7 +143,22 @@ def main():
     pipe = Pipeline(local_rank, n_ctx)
     pipe.set_bank(bank)
     scs, pages = [], None
-    for j in range(n_ctx):  # every rank (and every context of it) scans its own shard of the page set
+    shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM
+    if args.config == "c4":
+        from font_ocr_amd.shard import shard_range
+
+        first, last = shard_range(args.c4_pages, rank, world)
+        n_mine = last - first
+        shard_batches = [(b0, min(P, n_mine - b0)) for b0 in range(0, n_mine, P)]
+        host = synth_pages(bank, n_mine, R_W, R_H, first=first)
+        pages = host[:P]
+        shard = torch.from_numpy(host).to(dev)
+        del host
+        for j in range(n_ctx):
+            c_ = pipe.scanners[j]
+            c_.set_scan_cus(scan_cus)
+            scs.append(c_)
+    for j in range(n_ctx if shard is None else 0):  # every rank (and every context of it) scans its own shard of the page set
         if args.noise:
             pg = np.random.default_rng(1234 + rank * n_ctx + j).integers(0, 256, (P, R_H, R_W), dtype=np.uint8)
         else:
@@ -199,6 +236,7 @@ def main():
         slot_of, next_slot = {}, [0]
         threading.Thread(target=gather_worker, daemon=True).start()
 
+    first_page_is_seed0 = rank == 0  # rank 0's first page is synthetic page 0 = tests/golden/c2_page0.npz
     kern = {}
     phase = {}
     n_chars = 0
@@ -226,17 +264,25 @@ def main():
             pipe.release(t)
 
     def step(k):
-        if len(jobs) == n_ctx:  # the lane this step maps to still holds step k - n_ctx
+        if shard is not None:  # one step = the rank's whole shard, batch by batch, ingested device -> device from the resident tensor
+            for b0, nb in shard_batches:
+                submit_one(device_ptr=shard[b0].data_ptr(), shape=(nb, R_H, R_W))
+        else:
+            submit_one()
+
+    def submit_one(device_ptr=None, shape=None):
+        if len(jobs) == n_ctx:  # the lane this batch maps to still holds the batch submitted n_ctx submissions ago
             retire()
         if use_dist:
             slot = next_slot[0] % len(out_bufs)
             next_slot[0] += 1
             slot_free[slot].wait()  # its previous gather (2 * n_ctx steps ago) has read it
             slot_free[slot].clear()
-            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, chars_out=(out_bufs[slot].data_ptr(), out_bufs[slot].numel()))
+            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, chars_out=(out_bufs[slot].data_ptr(), out_bufs[slot].numel()),
+                            device_ptr=device_ptr, shape=shape)
             slot_of[t] = slot
         else:
-            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5)
+            t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, device_ptr=device_ptr, shape=shape)
         jobs.append(t)
 
     def fence():
@@ -256,9 +302,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed: the W warm-up steps, then — still untimed — more of the same steps until ~0.4 s of device work has gone by:
+    # the first scan of every context reads its result sizes synchronously (later ones run on those sizes), buffers grow to
+    # their steady size, and the GPU's clocks take a few hundred ms under load to settle; a 20-step timed region (~50 ms)
+    # measured right after 5 steps was 8 % below a 100-step one.
     for k in range(args.warmup):
         step(k)
     fence()
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle_s:
+        for k in range(2 * n_ctx):
+            step(k)
+        fence()
     timed = True
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -271,7 +326,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    total_px = world * P * R_W * R_H * args.steps
+    total_px = (args.c4_pages if shard is not None else world * P) * R_W * R_H * args.steps
     value = total_px / dt / 1e6
     e2e = e2e_pipe = None
     if args.with_upload:  # PCIe-inclusive rates (never the headline value)
@@ -340,13 +395,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if shard is not None else "weak",
         "vs_baseline": None,
         "dtype": "i8",
         "data": "synthetic",
         "config": {
             "workload": (f"BASELINE configs[1]: batches of {P} synthetic 608x720 pages, 95-glyph DejaVu Sans Mono 13px bank, "
                          "--x-bits 2 --y-bits 0 (380 templates), threshold 0.8, cap 1024, + process_hits(0.95, 5)") if args.config == "c2"
+                        else (f"BASELINE configs[3]: {args.c4_pages} synthetic 608x720 pages sharded over {world} rank(s) in contiguous blocks, each "
+                              f"rank's block HBM-resident and scanned in batches of {P}; 380 templates, threshold 0.8, cap 1024, "
+                              "+ process_hits(0.95, 5), RCCL gather of the match lists") if args.config == "c4"
                         else (f"BASELINE configs[2] geometry: batches of {P} synthetic 1200x1600 pages, 95-glyph bank, --x-bits 2 --y-bits 2 "
                               "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
             "pages_per_batch": P,
@@ -368,6 +426,9 @@ def main():
         name, k = max(kern.items(), key=lambda kv: kv[1]["alg"])
         avg_s = k["ms"] / k["n"] / 1e3
         achieved = 2.0 * k["alg"] / avg_s / 1e12
+        # SURVEY.md section 8(d) algorithmic bytes per launch: every page pixel once + 8 B per emitted match
+        alg_bytes = P * R_W * R_H + 8 * counters["raw_hits"]
+        traffic, traffic_src = (None, None) if args.noise else traffic_of(name, {"pages": P, "r_w": R_W, "r_h": R_H, "templates": len(bank)})
         out["roofline"] = {
             "bound": "mfma",
             "kernel": name,
@@ -375,7 +436,9 @@ def main():
             "peak": PEAK_I8_MFMA_TOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_I8_MFMA_TOPS, 4),
-            "traffic": traffic_of(name) if args.config == "c2" and not args.noise else None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "traffic_over_algorithmic_bytes": round(traffic / alg_bytes, 2) if traffic else None,
             "avg_kernel_ms": round(k["ms"] / k["n"], 4),
             "algorithmic_macs_per_launch": k["alg"],
             "issued_macs_per_launch": k["issued"],
@@ -402,14 +465,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # test infrastructure: the CPU baseline leg is allowed to use it
 
-        threads = min(len(os.sched_getaffinity(0)), 32)
+        threads = min(effective_cpus(), 32)
         S = args.cpu_sample_pages or min(P, 4 * threads)
         inv = (255 - pages[:S]).astype(np.uint8)
         use_ref = O.have_ref()
         passes = 2  # ~15 s of CPU work on the GPU box's 32 threads
         t0 = time.perf_counter()
         for _ in range(passes):
-            total, _, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
+            total, cpu_counts, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
         cdt = (time.perf_counter() - t0) / passes
         t0 = time.perf_counter()
         O.scan_pages_mt(inv[:2], bank, args.threshold, 1024, use_ref=use_ref, threads=1)  # single-core figure, 2 pages
@@ -424,16 +487,23 @@ def main():
             "value_1_core": round(2 * R_W * R_H / cdt1 / 1e6, 4),
         }
 
-    if rank == 0 and args.config == "c2" and not args.noise:
+    if rank == 0 and args.config in ("c2", "c4") and not args.noise and first_page_is_seed0:
         # parity in the same run: page 0 of this very batch against the committed reference golden (tests/golden/c2_page0.npz)
         try:
             g = np.load(os.path.join(ROOT, "tests", "golden", "c2_page0.npz"))
+            if shard is not None:  # c4: the context holds whichever batch it scanned last; put the shard's first batch back
+                sc.set_pages(pages)
             sc.scan(0.8, 1024, mode)
             offs, m = sc.matches()
             mine = m[: int(offs[len(bank)])]
-            same = np.array_equal(sc.counts()[0], g["counts"]) and mine.tobytes() == g["matches"].tobytes()
+            dev_counts = sc.counts()
+            same = np.array_equal(dev_counts[0], g["counts"]) and mine.tobytes() == g["matches"].tobytes()
             out["parity"] = (f"page 0: {len(mine)} raw matches bit-identical to the reference kernel's golden lists" if same
                              else "MISMATCH against tests/golden/c2_page0.npz")
+            if same and args.config == "c2" and "cpu_baseline" in out:  # the CPU leg scanned the first S pages of this very batch
+                S_ = cpu_counts.shape[0]
+                out["parity"] += (f"; per-(page, template) match counts of all {S_} pages of the CPU leg equal the device's ({int(cpu_counts.sum())} matches)"
+                                  if np.array_equal(dev_counts[:S_], cpu_counts) else "; MISMATCH of per-page counts against the CPU leg")
         except OSError:
             out["parity"] = "golden fixture not found"
 
