@@ -126,7 +126,7 @@ struct focr_ctx {
     int32_t post_overlap = 0;
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
     int prefilter = 0;                          // FOCR_PREFILTER_*: auto / single stage / two stages (focr_ctx_set_prefilter)
-    float *d_norms = nullptr;                   // two-stage path: window norms [super-class][page][Lrows][Lpitch][n_cls (+1)] f32
+    uint16_t *d_norms = nullptr;                // window norms as f16, planar: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
     size_t norms_bytes = 0;
     uint32_t *d_tglobal = nullptr;              // class-ordered -> global template index, 0xffffffff = never emits
     uint32_t *d_order_of = nullptr;             // global template index -> class-ordered index

@@ -54,6 +54,15 @@ static inline uint16_t bf16_round_up(double x) {
     return h;
 }
 
+// f32 -> f16 rounded towards zero -> f32, for values in f16's normal range (window norms: [0.04, 2886]) and 0
+static inline float f16_rtz(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u &= 0xffffe000u;  // drop the 13 mantissa bits f16 does not have
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // dense symmetric positive definite solve (Cholesky), n <= 32
 static bool cholesky(std::vector<double> &A, int n) {
     for (int j = 0; j < n; j++) {
@@ -411,10 +420,10 @@ extern "C" int focr_debug_lowrank(const focr_template_t *templates, size_t n_tem
             for (uint32_t j = 0; j < bh; j++)
                 for (uint32_t x = 0; x < bw; x++) s1 += a[j * fw + x], s2 += (uint64_t)a[j * fw + x] * a[j * fw + x];
             const uint64_t V = (uint64_t)bw * bh * s2 - s1 * s1;
-            nrm[v] = sqrtf((float)V * (1.0f / (float)(bw * bh)));
+            nrm[v] = f16_rtz(sqrtf((float)V * (1.0f / (float)(bw * bh))));  // the statistics kernel stores f16, rounded towards zero
             norm_exact[v] = std::sqrt((double)V / (double)(bw * bh));
         }
-        const float nF = nrm[lr.n_cls];
+        const float nF = nrm[lr.n_cls] * (1.f + 0x1p-10f + 0x1p-19f);  // upper bound from the stored lower bound
         // stage 1 (exact integers), bf16 of y, sum of squares in f32
         uint16_t zslot[LR_K];
         float ss = 0.f;
@@ -432,7 +441,7 @@ extern "C" int focr_debug_lowrank(const focr_template_t *templates, size_t n_tem
         for (uint32_t ci = 0; ci < lr.n_cls; ci++) {
             float th = 3.0e38f;
             uint32_t add = 0;
-            if (nrm[ci] > 0.f) th = thr_lo * nrm[ci], add = theta_add;
+            if (nrm[ci] > 0.f) th = thr_lo * (theta_add ? nrm[ci] * (1.f + 0x1p-10f + 0x1p-19f) : nrm[ci]), add = theta_add;
             uint32_t u;
             memcpy(&u, &th, 4);
             zslot[lr_extra_slot(2 + ci)] = (uint16_t)((u + add) >> 16);

@@ -80,7 +80,8 @@ struct MfmaLaunch {
 };
 
 // ---- two-stage prefilter (scan_mfma3.hip; host data: lowrank.hip) ----
-// Window norms of one super-class, planar: norms[v][page][Lrows][Lpitch] f32, value v = sqrt(V / n) of box v
+// Window norms of one super-class, planar: norms[v][page][Lrows][Lpitch] as f16 rounded towards zero (a lower bound of the
+// norm, at most 2^-10 below it), value v = sqrt(V / n) of box v
 // (V = n*s2 - s^2, exact integer).  Values 0 .. n_cls-1 are the super-class's size classes and carry the class's emit
 // flag in the sign (> 0: the reference can emit there: x, y >= 1, window inside the page, variance > 0; <= 0: never);
 // when no class has the frame's box, one more value holds the frame norm.  |value| is always the norm.
@@ -102,8 +103,8 @@ inline uint32_t lr_comp_slot(uint32_t j, uint32_t n_extras) {  // host: slot of 
 }
 
 struct Mfma3Args {
-    const float *norms;      // value 0 of the sub-batch's first page; values are `norm_stride` floats apart
-    size_t norm_stride;      // floats between consecutive values
+    const uint16_t *norms;   // f16 bits: value 0 of the sub-batch's first page; values are `norm_stride` elements apart
+    size_t norm_stride;      // elements between consecutive values
     uint32_t nv, n_cls, frame_value;  // frame_value: index of the value that holds the frame norm
     float inv_lambda;
     float thr_lo;            // thr_eff widened by 2^-20 away from the emitting side: theta = thr_lo * norm_c is a lower bound

@@ -141,16 +141,20 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             float Lf = __builtin_floorf(kq * __builtin_amdgcn_sqrtf(Vf)) - 2.0f;
             Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
             const bool emit = x_ok && y >= 1 && y + n_h <= r_h && nz;
-            int32_t out = emit ? -(int32_t)Lf : -REJECT;
-            if (NORMS) {
-                // norm = sqrt(V / n): relative error < 4 * 2^-24 (conversion, product with the rounded 1/n, 1-ulp sqrt)
-                float nrm = __builtin_amdgcn_sqrtf(Vf * kq);
-                if (mark && !emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
-                out = __float_as_int(nrm);
-            }
+            const int32_t out = emit ? -(int32_t)Lf : -REJECT;
             const uint64_t lm = __builtin_amdgcn_ballot_w64(emit);
             if (mark && mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
-            out_p[(size_t)k * Lpitch] = out;
+            if (NORMS) {
+                // norm = sqrt(V / n) as f16, rounded TOWARDS ZERO (v_cvt_pkrtz): the stored value is a lower bound of the norm,
+                // at most 2^-10 (+ 4 * 2^-24 from the f32 conversion, product with the rounded 1/n and 1-ulp sqrt) below it;
+                // norms lie in [sqrt(1/512), 2886]: always normal f16 numbers.  2 B per window and class instead of 4.
+                float nrm = __builtin_amdgcn_sqrtf(Vf * kq);
+                if (mark && !emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
+                const auto h2 = __builtin_amdgcn_cvt_pkrtz(nrm, 0.f);
+                reinterpret_cast<uint16_t *>(negL)[((size_t)page * Lrows + y) * Lpitch + x] = (uint16_t)(__builtin_bit_cast(uint32_t, h2) & 0xffffu);
+            } else {
+                out_p[(size_t)k * Lpitch] = out;
+            }
         }
         if (k + 1 < PER) {  // slide down one row
             s += H[r0 + k + n_h][col] - H[r0 + k][col];
@@ -451,7 +455,7 @@ static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t
 }
 
 // window norms of one box (a size class: mark = 1, or the two-stage prefilter's frame: mark = 0) into one plane of d_norms
-static int launch_norms(focr_ctx *c, uint32_t n_w, uint32_t n_h, float *plane, uint32_t Lpitch, uint32_t Lrows, uint8_t *live, uint32_t mtx,
+static int launch_norms(focr_ctx *c, uint32_t n_w, uint32_t n_h, uint16_t *plane, uint32_t Lpitch, uint32_t Lrows, uint8_t *live, uint32_t mtx,
                         uint32_t n_rows, uint32_t mark) {
     dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
     const float rn = 1.0f / (float)(n_w * n_h);
@@ -558,7 +562,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         std::vector<int> two(c->supers.size(), 0);
         std::vector<size_t> norm_off(c->supers.size(), 0);
         std::vector<uint32_t> norm_nv(c->supers.size(), 0);
-        size_t norm_floats = 0;
+        size_t norm_floats = 0;  // f16 values
         // two[si]: 0 = legacy path (per-class int32 negL tables, scan_mfma2_kernel: > 4 K-steps or > 4 size classes),
         //          1 = window norms (one fused statistics pass) + scan_mfma2s_kernel (one stage, roles swapped),
         //          2 = window norms + scan_mfma3_kernel (two stages)
@@ -578,13 +582,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             norm_off[si] = norm_floats;
             norm_floats += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernels are instantiated for 1 / 2 / 4 values
         }
-        if (c->norms_bytes < norm_floats * 4) {
+        if (c->norms_bytes < norm_floats * 2) {
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
             if (c->d_norms) (void)hipFree(c->d_norms);
             c->d_norms = nullptr;
             c->norms_bytes = 0;
-            if (hipMalloc((void **)&c->d_norms, norm_floats * 4) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(norms) failed");
-            c->norms_bytes = norm_floats * 4;
+            if (hipMalloc((void **)&c->d_norms, norm_floats * 2) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(norms) failed");
+            c->norms_bytes = norm_floats * 2;
         }
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];

@@ -254,9 +254,9 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         float nrm[MT][NV];  // norms of the lane's own window px + r, one per size class
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const float *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+            const uint16_t *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
 #pragma unroll
-            for (int v = 0; v < NV; v++) nrm[mt][v] = np[(size_t)v * P.norm_stride];
+            for (int v = 0; v < NV; v++) nrm[mt][v] = (float)__builtin_bit_cast(_Float16, np[(size_t)v * P.norm_stride]);  // f16, a lower bound
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
         float nrm[MT][NV];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const float *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+            const uint16_t *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
 #pragma unroll
-            for (int v = 0; v < NV; v++) nrm[mt][v] = np[(size_t)v * P.norm_stride];
+            for (int v = 0; v < NV; v++) nrm[mt][v] = (float)__builtin_bit_cast(_Float16, np[(size_t)v * P.norm_stride]);  // f16, a lower bound
         }
         // A fragments (as scan_mfma2.hip): lane (r, g) of K-step ks holds the 16 bytes of k-group 4*ks+g of window px+r
         v4i afrag[MT][KSTEPS];
@@ -208,8 +208,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
             float nF = 0.f;
 #pragma unroll
             for (int v = 0; v < NV; v++) nF = ((uint32_t)v == P.frame_value) ? __builtin_fabsf(nrm[mt][v]) : nF;
-            // R >= sqrt(N_F^2 - |P(a - mean)|^2): N_F^2 widened by 2^-20 (the norm carries < 4 * 2^-24 of error), the
+            // R >= sqrt(N_F^2 - |P(a - mean)|^2): N_F (widened above to an upper bound) squared and widened by 2^-20, the
             // subtrahend already narrowed by inv_lambda's margin; sqrt 1 ulp + its own product: another 2^-20
+            nF *= 1.f + 0x1p-10f + 0x1p-19f;  // the stored f16 norm is a lower bound, at most 2^-10 (+ f32 roundings) below the norm
             const float nF2 = nF * nF * (1.f + 0x1p-20f);
             float R = __builtin_amdgcn_sqrtf(__builtin_fmaxf(__builtin_fmaf(-ss, P.inv_lambda, nF2), 0.f)) * (1.f + 0x1p-20f);
             // extras as f32 bit patterns already rounded in the safe direction at bit 16 (bf16 = the high half):
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
                 if (ci < NV && (uint32_t)ci < P.n_cls) {
                     const float nc = nrm[mt][ci < NV ? ci : 0];
                     if (nc > 0.f) {
-                        th = P.thr_lo * nc;
+                        // lower bound of thr * norm_c: the stored norm is a lower bound (fine for thr >= 0); a negative
+                        // threshold needs the upper bound of the norm
+                        th = P.thr_lo * (P.theta_add ? nc * (1.f + 0x1p-10f + 0x1p-19f) : nc);
                         add = P.theta_add;
                     }
                 }
