@@ -160,6 +160,10 @@ def _load(name, symbols, mode=C.DEFAULT_MODE):
     if name in _cache:
         return _cache[name]
     path = os.path.join(LIB_DIR, name)
+    # FOCR_HOST_LIB_DIR: an alternative build of the CPU-side libraries (make asan), for the sanitizer test run
+    alt = os.environ.get("FOCR_HOST_LIB_DIR")
+    if alt and name != "libfocr_hip.so" and os.path.exists(os.path.join(alt, name)):
+        path = os.path.join(alt, name)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build the native libraries first "

@@ -3,9 +3,11 @@
 //
 // One call = one template over one page, with the caller's window tables
 // (patch_sum, patch_rnorm, start_end) honoured exactly as the reference kernel
-// reads them.  This entry point exists for drop-in linkage and parity testing;
-// throughput goes through the batched API (a single call moves 13 B/px of
-// tables over PCIe).
+// reads them.  The page and the tables stay resident per calling thread and are
+// uploaded again only when their content changes (64-bit content hash), so the
+// reference's own call pattern — hundreds of templates over one page — pays the
+// 13 B/px of PCIe traffic once per page and size class, not once per call.
+// Throughput proper goes through the batched API.
 #include <cmath>
 #include <cstring>
 
@@ -17,10 +19,16 @@ int sort_pairs_u64_f32(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, float 
                        unsigned end_bit);
 int ensure_hit_capacity(focr_ctx *c, size_t want);
 
-// one lane per window (x, y), x in [start_y, end_y), y in [1, y_searches)
+typedef int v4i_c __attribute__((ext_vector_type(4), aligned(1)));
+typedef int v2i_c __attribute__((ext_vector_type(2), aligned(1)));
+
+// one lane per window (x, y), x in [start_y, end_y), y in [1, y_searches): the padded needle row (N = 8 or 16 bytes, zero
+// past n_w as the caller built it, src/ncc.rs:925-935) against the N bytes at the window's row start, v_dot4_u32_u8.  Like the
+// reference kernel the loads run up to N - n_w bytes past the window (src/ncc.cpp:315-318 loads 16 bytes whatever n_w is);
+// those bytes meet the needle's zero padding.  d_ref carries 64 spare bytes behind the page.
 template <int N>
 __global__ __launch_bounds__(256) void compat_kernel(const uint8_t *__restrict__ ref, uint32_t r_w, uint32_t r_h,
-                                                     const uint8_t *__restrict__ needle, uint32_t n_w, uint32_t n_h,
+                                                     const uint32_t *__restrict__ needle, uint32_t n_w, uint32_t n_h,
                                                      const uint32_t *__restrict__ patch_sum,
                                                      const double *__restrict__ patch_rnorm,
                                                      const uint16_t *__restrict__ start_end, double s_n, double n_recip,
@@ -32,10 +40,18 @@ __global__ __launch_bounds__(256) void compat_kernel(const uint8_t *__restrict__
     const uint32_t start = start_end[2 * y], end = start_end[2 * y + 1];
     if (x < start || x >= end || x + n_w > r_w) return;  // the last clause only guards insane caller tables
     uint32_t acc = 0;
-    for (uint32_t j = 0; j < n_h; j++) {
-        const uint8_t *r = ref + (size_t)(y + j) * r_w + x;
-        const uint8_t *t = needle + j * N;
-        for (uint32_t i = 0; i < n_w; i++) acc += (uint32_t)t[i] * (uint32_t)r[i];  // padded columns are zero
+    const uint8_t *r = ref + (size_t)y * r_w + x;
+    for (uint32_t j = 0; j < n_h; j++, r += r_w) {
+        const uint32_t *t = needle + j * (N / 4);  // uniform address: scalar loads
+        if (N == 8) {
+            const v2i_c w = *reinterpret_cast<const v2i_c *>(r);
+            acc = __builtin_amdgcn_udot4((uint32_t)w[0], t[0], acc, false);
+            acc = __builtin_amdgcn_udot4((uint32_t)w[1], t[1], acc, false);
+        } else {
+            const v4i_c w = *reinterpret_cast<const v4i_c *>(r);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_udot4((uint32_t)w[k], t[k], acc, false);
+        }
     }
     const size_t o = (size_t)y * r_w + x;
     const double sim = ncc_similarity(acc, patch_sum[o], s_n, n_recip, rnorm_n, patch_rnorm[o]);
@@ -59,8 +75,34 @@ __global__ void compat_pack(const uint64_t *__restrict__ keys, const float *__re
     out[i] = m;
 }
 
+// 64-bit content hash (4 interleaved multiply-rotate lanes over 8-byte words): ~10 GB/s on one core, i.e. 0.5 ms for the
+// 5.7 MB a 608x720 page's inputs have — against ~2 ms to push them over PCIe from pageable memory
+static uint64_t content_hash(const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0x2545f4914f6cdd1dull};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int k = 0; k < 4; k++) {
+            uint64_t v;
+            memcpy(&v, b + i + 8 * k, 8);
+            h[k] = (h[k] ^ v) * 0x9fb21c651e98df25ull;
+            h[k] = (h[k] << 29) | (h[k] >> 35);
+        }
+    uint64_t tail = 0;
+    for (int sh = 0; i < n; i++, sh = (sh + 8) & 63) tail ^= (uint64_t)b[i] << sh;
+    uint64_t r = h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ tail ^ (uint64_t)n * 0xd6e8feb86659fd93ull;
+    r ^= r >> 32;
+    r *= 0xd6e8feb86659fd93ull;
+    return r ^ (r >> 29);
+}
+
 struct CompatState {
     focr_ctx *ctx = nullptr;
+    // what is resident on the device: the reference's host calls ncc_N_u8 once per template with the SAME page, and the
+    // same window tables for every template of a size class (src/ncc.rs:264-268, 332-404), so each input is hashed and
+    // uploaded again only when its content (or geometry) changed
+    uint64_t h_ref = 0, h_ps = 0, h_pr = 0, h_se = 0;
+    size_t res_w = 0, res_h = 0;
     uint8_t *d_ref = nullptr, *d_needle = nullptr;
     uint32_t *d_ps = nullptr;
     double *d_pr = nullptr;
@@ -117,9 +159,11 @@ static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *n
         tl.d_pr = nullptr;
         tl.px_alloc = 0;
         CK(hipMalloc(&tl.d_ref, npx + 64));
+        CK(hipMemsetAsync(tl.d_ref, 0, npx + 64, c->stream));
         CK(hipMalloc(&tl.d_ps, npx * 4));
         CK(hipMalloc(&tl.d_pr, npx * 8));
         tl.px_alloc = npx;
+        tl.res_w = tl.res_h = 0;  // nothing resident in the new buffers
     }
     if (tl.rows_alloc < r_h) {
         CK(hipStreamSynchronize(c->stream));
@@ -127,6 +171,7 @@ static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *n
         tl.d_se = nullptr;
         CK(hipMalloc(&tl.d_se, r_h * 2 * sizeof(uint16_t)));
         tl.rows_alloc = r_h;
+        tl.res_w = tl.res_h = 0;
     }
     if (!tl.d_needle) CK(hipMalloc(&tl.d_needle, 16 * 65536));
     if (n_h * N > 16 * 65536) {
@@ -146,10 +191,17 @@ static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *n
     const double rnorm_n = 1. / std::sqrt(norm2_n);
     const double n_recip = 1. / (double)n;
 
-    CK(hipMemcpyAsync(tl.d_ref, reference, npx, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemcpyAsync(tl.d_ps, patch_sum, npx * 4, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemcpyAsync(tl.d_pr, patch_rnorm, npx * 8, hipMemcpyHostToDevice, c->stream));
-    CK(hipMemcpyAsync(tl.d_se, start_end, r_h * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    {
+        const bool geo = tl.res_w != r_w || tl.res_h != r_h;
+        const uint64_t hr = content_hash(reference, npx), hs = content_hash(patch_sum, npx * 4), hp = content_hash(patch_rnorm, npx * 8),
+                       he = content_hash(start_end, r_h * 2 * sizeof(uint16_t));
+        if (geo || hr != tl.h_ref) CK(hipMemcpyAsync(tl.d_ref, reference, npx, hipMemcpyHostToDevice, c->stream));
+        if (geo || hs != tl.h_ps) CK(hipMemcpyAsync(tl.d_ps, patch_sum, npx * 4, hipMemcpyHostToDevice, c->stream));
+        if (geo || hp != tl.h_pr) CK(hipMemcpyAsync(tl.d_pr, patch_rnorm, npx * 8, hipMemcpyHostToDevice, c->stream));
+        if (geo || he != tl.h_se) CK(hipMemcpyAsync(tl.d_se, start_end, r_h * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        tl.h_ref = hr, tl.h_ps = hs, tl.h_pr = hp, tl.h_se = he;
+        tl.res_w = r_w, tl.res_h = r_h;
+    }
     CK(hipMemcpyAsync(tl.d_needle, needle_u8, n_h * N, hipMemcpyHostToDevice, c->stream));
 
     size_t want = std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 16, n_out * 4));
@@ -158,7 +210,7 @@ static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *n
         CK(hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
         dim3 grid((unsigned)((r_w + 255) / 256), (unsigned)(y_searches - 1));
         hipLaunchKernelGGL((compat_kernel<N>), grid, dim3(256), 0, c->stream, tl.d_ref, (uint32_t)r_w, (uint32_t)r_h,
-                           tl.d_needle, (uint32_t)n_w, (uint32_t)n_h, tl.d_ps, tl.d_pr, tl.d_se, (double)s_n, n_recip,
+                           reinterpret_cast<const uint32_t *>(tl.d_needle), (uint32_t)n_w, (uint32_t)n_h, tl.d_ps, tl.d_pr, tl.d_se, (double)s_n, n_recip,
                            rnorm_n, (double)threshold, c->d_hit_keys, c->d_hit_sims, (unsigned long long *)c->d_counter,
                            (unsigned long long)c->hit_capacity);
         CK(hipGetLastError());

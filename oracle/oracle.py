@@ -34,7 +34,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("FOCR_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # FOCR_ORACLE_LIB: the `make asan` build
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

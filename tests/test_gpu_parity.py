@@ -800,3 +800,35 @@ def test_size_estimates_and_redo_on_overflow(bank_x2, mode):
         sc.process_hits(0.9, 5)
         check("sparse")
         assert sc.lines_flat().tobytes() == lines_a.tobytes()
+
+
+def test_compat_symbols_in_the_reference_call_pattern(bank_x2):
+    """The unmodified reference host calls ncc_8_u8 / ncc_16_u8 once per template with the same page and, per size class,
+    the same window tables (src/ncc.rs:332-404, 587-701).  All 380 calls of one 608x720 page through the drop-in symbols:
+    identical lists, and — page and tables stay resident on the device between calls — faster than the reference's own
+    kernel on one host core."""
+    import time
+
+    page = synth_page(bank_x2, SYNTH_SEED_BASE + 77, 608, 720)
+    inv = O.invert(page)
+    flat = O.padded(inv)
+    tabs = O.tables(inv)
+    stats = {}
+    for t in range(len(bank_x2)):
+        nd = bank_x2.needle(t)
+        if nd.shape not in stats:
+            stats[nd.shape] = O.prepare_for_size(inv, nd.shape[1], nd.shape[0], tabs)
+    searcher = Searcher(inv)
+    searcher.search_c_u8(bank_x2.needle(1), stats[bank_x2.needle(1).shape], 0.8)  # context creation, first upload
+    t0 = time.perf_counter()
+    got = [searcher.search_c_u8(bank_x2.needle(t), stats[bank_x2.needle(t).shape], 0.8) for t in range(len(bank_x2))]
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = [O.ncc_u8(flat, 608, 720, bank_x2.needle(t), stats[bank_x2.needle(t).shape], 0.8, 1024, use_ref=O.have_ref()) for t in range(len(bank_x2))]
+    t_ref = time.perf_counter() - t0
+    assert sum(len(w) for w in want) > 15000
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert g.tobytes() == w.tobytes(), t
+    if O.have_ref():
+        assert t_gpu < t_ref, (t_gpu, t_ref)
+    print(f"380 drop-in calls: {t_gpu * 1e3:.0f} ms on the device path, {t_ref * 1e3:.0f} ms with the reference kernel on one core")
