@@ -4,24 +4,29 @@
 //     sim = num / (norm_n * norm_p),  num = sum_k a_k b_k - s_n s_p / n = sum_k a_k (b_k - mean_t)
 // and emits iff sim > thr.  Almost no (w, t) pair passes, so the device splits the work:
 //
-//  1. window statistics (stats_kernel): per size class and window, the exact integer sums s_p, s2_p
-//     and  negL(w) = -floor(kappa * norm_p(w)) , or -REJECT for windows the reference never emits
-//     (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN, src/ncc.rs:309-311).
-//  2. MFMA prefilter (scan_mfma_kernel): every template is mean-centred, scaled by a bank-wide
+//  1. window statistics (stats_kernel): per size class and window, the exact integer sums s_p, s2_p and
+//     V = n*s2 - s^2; stored per window: the f16 norm sqrt(V / n) rounded towards zero, its sign = "the reference never
+//     emits here" (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN, src/ncc.rs:309-311).  (Legacy form, still
+//     used for size classes with more than 4 K-steps: negL(w) = -floor(kappa * norm_p(w)) as int32, or -REJECT.)
+//  2. MFMA prefilter (scan_mfma2.hip): every template is mean-centred, scaled by a bank-wide
 //     constant c/norm_n(t) and rounded to int8 with the rounding chosen so that sum_k bq_k = 0.
 //     G(w,t) = sum_k (a_k - 128) bq_k  (= sum_k a_k bq_k) is one v_mfma_i32_16x16x64_i8 chain over
-//     the window's bytes (M = 16 windows, N = 16 templates, K = 64 bytes per instruction) with
-//     C-in = negL(w), so "D > 0" <=> G > kappa*norm_p.  Cauchy-Schwarz bounds the rounding error:
+//     the window's bytes (16 templates x 16 windows, K = 64 bytes per instruction) with
+//     C-in = -(floor(kappa*norm_p(w)) - 2), so "D > 0" <=> G > kappa*norm_p.  Cauchy-Schwarz bounds the rounding error:
 //         | c*num/norm_n - G | = | sum_k (a_k - mean_w) e_k | <= norm_p * ||e_t||_2
 //     hence sim > thr  ==>  G > (c*thr - max_t ||e_t||) * norm_p =: kappa * norm_p.  The filter
 //     has no false negatives; kappa carries an extra relative margin for the f64 roundings of
-//     the exact formula.  Survivors (a few per 10^5 pairs) go to a candidate list.
+//     the exact formula, and a stored norm below the true one only lowers the threshold.  Survivors (a few per 10^5
+//     pairs) go to a candidate list.  (FOCR_PREFILTER_TWO_STAGE puts a low-rank bound in front: scan_mfma3.hip.)
 //  3. exact verify (verify_kernel): the reference formula, operation for operation (common.h),
-//     on every candidate -> unordered hit list -> order.hip.
+//     on every candidate -> flags -> order.hip.
 //
-// Layout: A operand = windows, B operand = the quantised bank staged once per block in LDS in exactly the
-// per-lane order the MFMA wants; the K layouts (how image rows map to 16-byte k-groups) are in mfma_common.h.
-// The kernel itself is in scan_mfma2.hip.
+// Sizes: every phase behind the scan kernel takes its element count from device memory; exact / estimated mode: see
+// launch_scan_mfma and ctx.hip (finish_results).
+//
+// Layout: one operand = windows (fragments straight from the page), the other = the quantised bank staged once per
+// block in LDS in exactly the per-lane order the MFMA wants; the K layouts (how image rows map to 16-byte k-groups) are
+// in mfma_common.h.  The scan kernels are in scan_mfma2.hip / scan_mfma3.hip.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
