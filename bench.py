@@ -253,8 +253,8 @@ def main():
         t = jobs.popleft()
         c_ = pipe.wait(t)
         if timed:
-            for li in c_.launches():
-                k = kern.setdefault(li["name"], dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
+            for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
+                k = kern.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
                 k["ms"] += li["ms"]
                 k["n"] += 1
             for k_, v in c_.timings().items():
@@ -386,7 +386,7 @@ def main():
             run_step(sc)
             if i >= 2:
                 for li in sc.launches():
-                    k = iso.setdefault(li["name"], dict(ms=0.0, n=0))
+                    k = iso.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0))
                     k["ms"] += li["ms"]
                     k["n"] += 1
         sc.set_scan_cus(scan_cus)
@@ -429,7 +429,8 @@ def main():
         out["data"] = "uniform random noise pages (worst case, no hits)"
     if rank == 0:
         # dominant kernel = the scan launch with the most algorithmic work
-        name, k = max(kern.items(), key=lambda kv: kv[1]["alg"])
+        key, k = max(kern.items(), key=lambda kv: kv[1]["alg"])
+        name = key[0]
         avg_s = k["ms"] / k["n"] / 1e3
         achieved = 2.0 * k["alg"] / avg_s / 1e12
         # SURVEY.md section 8(d) algorithmic bytes per launch: every page pixel once + 8 B per emitted match
@@ -456,8 +457,8 @@ def main():
             # per-launch durations stretch when launches of several contexts share the chip; two more readings:
             step_alg = sum(v["alg"] * v["n"] for v in kern.values()) / args.steps  # algorithmic MACs per step, all scan launches
             out["roofline"]["frac_whole_step"] = round(2.0 * step_alg / (dt / args.steps) / 1e12 / PEAK_I8_MFMA_TOPS, 4)
-            if name in iso:
-                iso_ms = iso[name]["ms"] / iso[name]["n"]
+            if key in iso:
+                iso_ms = iso[key]["ms"] / iso[key]["n"]
                 out["roofline"]["isolated_avg_kernel_ms"] = round(iso_ms, 4)
                 out["roofline"]["frac_isolated"] = round(2.0 * k["alg"] / (iso_ms / 1e3) / 1e12 / PEAK_I8_MFMA_TOPS, 4)
             out["roofline"]["note"] += (f"; {n_ctx} batches in flight: 'achieved'/'frac' use the per-launch duration inside the timed region "
@@ -465,7 +466,10 @@ def main():
                                         "'frac_isolated' = same kernel alone on all CUs (extra untimed leg), "
                                         "'frac_whole_step' = algorithmic ops of one step / wall time of one step")
         out["phases_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in phase.items()}
-        out["kernels_ms_per_step"] = {n_: round(v["ms"] / args.steps, 4) for n_, v in kern.items()}
+        per_name = {}
+        for (n_, _alg), v in kern.items():
+            per_name[n_] = per_name.get(n_, 0.0) + v["ms"] / args.steps
+        out["kernels_ms_per_step"] = {n_: round(v, 4) for n_, v in per_name.items()}
         out["work"] = {"candidates": counters["candidates"], "raw_hits": counters["raw_hits"], "chars_out": int(n_chars)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -117,7 +117,7 @@ struct Mfma3Args {
 uint32_t mfma3_chunk_tiles(uint32_t ksteps);
 int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus);
 // scan_mfma2.hip
-size_t mfma2_bank_budget();
+uint32_t mfma2_chunk_tiles(uint32_t ksteps);
 int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus);  // roles swapped, norms instead of negL
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);
 

@@ -648,7 +648,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            const uint32_t chunk_tiles = two[si] == 2 ? mfma3_chunk_tiles(su.ksteps) : (uint32_t)(mfma2_bank_budget() / (su.ksteps * 1024));
+            const uint32_t chunk_tiles = two[si] == 2 ? mfma3_chunk_tiles(su.ksteps) : mfma2_chunk_tiles(su.ksteps);
             uint32_t t0 = 0;
             while (t0 < su.n_tiles) {
                 MfmaLaunch L{};

@@ -20,9 +20,14 @@ typedef int v3i __attribute__((ext_vector_type(3)));
 typedef v3i v3i_u __attribute__((aligned(1)));
 typedef int int_u __attribute__((aligned(1)));
 
-constexpr size_t V2_BANK_BUDGET = 136 << 10;  // one block per CU: the rest of the 160 KiB holds staging buffers + template ids
-
-size_t mfma2_bank_budget() { return V2_BANK_BUDGET; }
+// N-tiles of one launch: the whole 160 KiB of a CU's LDS belong to its one workgroup — ksteps KiB of quantised templates
+// + 64 B of template ids per tile, next to the waves' candidate staging buffers.  As few launches per super-class as
+// possible: every launch re-loads the window fragments (BASELINE configs[2]'s 95 N-tiles at 3 K-steps: 49 + 46 tiles in two
+// launches instead of the three a 136 KiB budget gave).
+uint32_t mfma2_chunk_tiles(uint32_t ksteps) {
+    const size_t fixed = (size_t)16 * WBUF * 8 + 256;
+    return (uint32_t)(((160u << 10) - fixed) / ((size_t)ksteps * 1024 + 64));
+}
 
 template <int KSTEPS, int RPG, int MT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
