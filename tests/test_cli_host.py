@@ -107,3 +107,42 @@ def test_line_text_and_space_extension():
     buf = C.create_string_buffer(6)
     assert host.focr_line_text(line.ctypes.data_as(C.c_void_p), len(line), adv, 1, buf, 6) == need
     assert buf.value == b"abc d"
+
+
+def test_image_probe_and_decode_into_caller_memory(tmp_path):
+    """focr_image_probe (header only) and focr_image_load_luma8_into (the `ncc` binary's decoders write straight into
+    page-locked batch slabs): PGM in place, other formats through the general decoder, too-small slots refused."""
+    import ctypes as C
+
+    from font_ocr_amd import _native as N
+
+    host = N.host()
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (31, 45), dtype=np.uint8)
+    save_pgm(tmp_path / "a.pgm", img)
+    with open(tmp_path / "c.pgm", "wb") as f:  # comment lines in the header, payload right after one whitespace byte
+        f.write(b"P5\n# made by hand\n45 31\n# another\n255\n" + img.tobytes())
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(31))
+    import struct
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(tmp_path / "b.png", "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 45, 31, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    err = C.create_string_buffer(256)
+    for name in ("a.pgm", "c.pgm", "b.png"):
+        w, h = C.c_size_t(), C.c_size_t()
+        assert host.focr_image_probe(str(tmp_path / name).encode(), C.byref(w), C.byref(h), err, 256) == 0, err.value
+        assert (w.value, h.value) == (45, 31)
+        dst = np.full(45 * 31 + 7, 0xAB, np.uint8)
+        w2, h2 = C.c_size_t(), C.c_size_t()
+        assert host.focr_image_load_luma8_into(str(tmp_path / name).encode(), dst.ctypes.data, 45 * 31, C.byref(w2), C.byref(h2), err, 256) == 0, err.value
+        assert (w2.value, h2.value) == (45, 31)
+        assert np.array_equal(dst[: 45 * 31].reshape(31, 45), img) and (dst[45 * 31:] == 0xAB).all(), name
+        assert host.focr_image_load_luma8_into(str(tmp_path / name).encode(), dst.ctypes.data, 45 * 31 - 1, C.byref(w2), C.byref(h2), err, 256) != 0
+    with open(tmp_path / "t.pgm", "wb") as f:
+        f.write(b"P5\n45 31\n255\n" + img.tobytes()[:-5])
+    assert host.focr_image_load_luma8_into(str(tmp_path / "t.pgm").encode(), dst.ctypes.data, 45 * 31, C.byref(w2), C.byref(h2), err, 256) != 0
+    assert b"truncated" in err.value
+    assert host.focr_image_probe(str(tmp_path / "missing.pgm").encode(), C.byref(w), C.byref(h), err, 256) != 0
