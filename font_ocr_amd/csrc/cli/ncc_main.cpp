@@ -492,6 +492,13 @@ int main(int argc, char **argv) {
         for (size_t k = 0; k < B.n; k++) {  // output, src/ncc.rs:849-877
             for (uint64_t l = page_off[k]; l < page_off[k + 1]; l++) {
                 const size_t nq = line_off[l + 1] - line_off[l];
+                if (args.verbose) {  // process_hits' per-line histogram of the x distance between consecutive characters (src/ncc.rs:767-778)
+                    std::map<int, int> dx_counts;
+                    for (uint64_t q = line_off[l] + 1; q < line_off[l + 1]; q++) dx_counts[(int)chars[q].x - (int)chars[q - 1].x]++;
+                    std::string h = "{";
+                    for (auto &kv : dx_counts) h += (h.size() > 1 ? ", " : "") + std::to_string(kv.first) + ": " + std::to_string(kv.second);
+                    fprintf(stderr, "%s}\n", h.c_str());
+                }
                 if (!args.csv) {
                     const size_t at = out.size();
                     out.resize(at + 4 * nq + (args.spaces ? 4096 : 0) + 1);
