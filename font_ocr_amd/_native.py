@@ -161,6 +161,8 @@ def _load(name, symbols, mode=C.DEFAULT_MODE):
         return _cache[name]
     path = os.path.join(LIB_DIR, name)
     # FOCR_HOST_LIB_DIR: an alternative build of the CPU-side libraries (make asan), for the sanitizer test run
+    if name == "libfocr_hip.so" and os.environ.get("FOCR_HIP_LIB"):  # an experiment build of the HIP library (tools/)
+        path = os.environ["FOCR_HIP_LIB"]
     alt = os.environ.get("FOCR_HOST_LIB_DIR")
     if alt and name != "libfocr_hip.so" and os.path.exists(os.path.join(alt, name)):
         path = os.path.join(alt, name)
