@@ -338,29 +338,30 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                     m = max(max(m, acc[mt][2]), acc[mt][3]);
                 }
                 if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
+                    // The candidate path costs 0.33 of the kernel's 2.3 ms at C2 (3.8 M candidates; threshold sweep in
+                    // DESIGN.md), so it is kept short: ONE LDS read per visit for the lane's four template ids (lane (r, g),
+                    // register i: template 4g + i of the tile, window px + r; ~0 = dead / padding, never emits), one ballot per
+                    // register, and a key that is a scalar base per M-tile plus two lane terms.
+                    const v4i tg4 = reinterpret_cast<const v4i *>(tg_lds)[nt * 4 + g];
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
                         if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
+                        uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
+                        asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
+                        const uint64_t kbase = fmt.pack(page_base + pg, yy, xx, 0) + ((uint64_t)r << fmt.bt);  // x = px + r < 2^bx: no carry into y
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const bool f = acc[mt][i] > 0;
-                            const uint64_t mask = __builtin_amdgcn_ballot_w64(f);
-                            if (!mask) continue;  // wave-uniform
-                            // lane (r, g), register i: template 4g + i of the tile, window px + r
-                            const uint32_t tg = f ? tg_lds[nt * 16 + 4 * g + i] : 0xffffffffu;
-                            const bool ok = tg != 0xffffffffu;  // dead / padding templates never emit
+                            const bool ok = acc[mt][i] > 0 && tg4[i] != -1;
                             const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+                            if (!okmask) continue;  // wave-uniform
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
-                            if (!cnt) continue;
                             if (wcount + cnt > WBUF) {
                                 flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
                                 wcount = 0;
                             }
                             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
-                            uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
-                            asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
-                            if (ok) wbuf[wcount + pos] = fmt.pack(page_base + pg, yy, xx + r, tg);
+                            if (ok) wbuf[wcount + pos] = kbase + (uint32_t)tg4[i];
                             wcount += cnt;
                         }
                     }
