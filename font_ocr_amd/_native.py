@@ -153,6 +153,14 @@ RASTER_SYMBOLS = {
                                    C.c_int, C.c_uint32, C.c_uint32, C.POINTER(BankStruct), C.c_char_p, C.c_size_t]),
 }
 
+# include/focr_rccl.h (libfocr_rccl.so)
+RCCL_SYMBOLS = {
+    "focr_gather_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "focr_gather_destroy": (None, [C.c_void_p]),
+    "focr_gather_last_error": (C.c_char_p, []),
+    "focr_gather_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]),
+}
+
 _cache = {}
 
 
@@ -192,3 +200,8 @@ def host():
 
 def raster():
     return _load("libfocr_raster.so", RASTER_SYMBOLS)
+
+
+def rccl():
+    """libfocr_rccl.so — the match-list gather over RCCL for one process driving several GPUs (loads librccl)."""
+    return _load("libfocr_rccl.so", RCCL_SYMBOLS)

@@ -45,6 +45,17 @@ def test_host_libraries_export_every_declared_symbol():
     N.raster()
 
 
+def test_rccl_library_exports_every_declared_symbol():
+    """include/focr_rccl.h: checked with nm only — loading the library pulls in librccl, which the CPU tests avoid."""
+    declared = _declared("focr_rccl.h")
+    assert declared == set(N.RCCL_SYMBOLS), declared ^ set(N.RCCL_SYMBOLS)
+    path = os.path.join(N.LIB_DIR, "libfocr_rccl.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "font_ocr_amd", "csrc"), "rccl"], check=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    assert declared <= set(re.findall(r" T (focr_\w+)", out))
+
+
 def test_no_cpu_fallback_without_device(hip_lib):
     from font_ocr_amd.searcher import FocrError, Scanner
 

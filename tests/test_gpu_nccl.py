@@ -71,3 +71,47 @@ print("NCCL_GATHER_OK", total)
 def test_rccl_gather_of_device_resident_characters():
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "NCCL_GATHER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+NATIVE_CHILD = r'''
+import ctypes as C, os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+from font_ocr_amd import Bank, synth_pages, _native as N
+from font_ocr_amd.bank import HIT_DTYPE
+from font_ocr_amd.searcher import SCAN_MFMA, Scanner
+
+R = N.rccl()
+g = C.c_void_p()
+devs = (C.c_int * 1)(0)
+assert R.focr_gather_create(devs, 1, C.byref(g)) == 0, R.focr_gather_last_error()
+bank = Bank.load(os.path.join(sys.argv[1], "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
+sub = bank.subset(list(range(33, 80)) + list(range(95 + 33, 95 + 80)))
+with Scanner(0) as sc:
+    sc.set_bank(sub)
+    sc.set_pages(synth_pages(bank, 3, 300, 130, first=70))
+    sc.scan(0.8, 1024, SCAN_MFMA)
+    sc.process_hits(0.95, 5)
+    want = sc.lines_flat().copy()
+    ptr, n = sc.device_chars()
+    nbytes = n * HIT_DTYPE.itemsize
+    dst = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    src = (C.c_void_p * 1)(ptr)
+    sizes = (C.c_size_t * 1)(nbytes)
+    assert R.focr_gather_bytes(g, src, sizes, C.c_void_p(dst.data_ptr()), dst.numel()) == 0, R.focr_gather_last_error()
+    got = np.frombuffer(dst[:nbytes].cpu().numpy().tobytes(), dtype=HIT_DTYPE)
+    assert got.tobytes() == want.tobytes() and len(want) > 100
+    assert R.focr_gather_bytes(g, src, sizes, C.c_void_p(dst.data_ptr()), nbytes - 1) != 0  # destination too small
+R.focr_gather_destroy(g)
+print("NATIVE_GATHER_OK", len(want))
+'''
+
+
+def test_native_rccl_gather_single_process():
+    """libfocr_rccl.so (include/focr_rccl.h): ncclCommInitAll + grouped ncclSend / ncclRecv of a context's device-resident
+    characters to rank 0 — the single-process multi-GPU form of the path's one collective, here with the one GPU the
+    test box has (rank 0 sends to itself)."""
+    r = subprocess.run([sys.executable, "-c", NATIVE_CHILD, ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NATIVE_GATHER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
