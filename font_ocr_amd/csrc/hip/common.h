@@ -88,6 +88,11 @@ struct KeyFmt {
 
 }  // namespace focr
 
+// Item queues of the persistent scan kernels (scan_mfma2.hip): one per launch, QUEUE_XCDS counters QUEUE_STRIDE dwords
+// apart, all zeroed by the one memset that clears the counters at the start of a scan.
+constexpr uint32_t COUNTER_WORDS = 64, QUEUE_XCDS = 8, QUEUE_STRIDE = 32, MAX_SCAN_QUEUES = 128;
+constexpr size_t COUNTER_BYTES = (COUNTER_WORDS + (size_t)MAX_SCAN_QUEUES * QUEUE_XCDS * QUEUE_STRIDE) * sizeof(uint32_t);
+
 struct focr_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -154,7 +159,8 @@ struct focr_ctx {
     size_t hit_capacity = 0;     // entries in d_hit_keys / d_hit_sims
     uint64_t *d_hit_keys = nullptr, *d_hit_keys_alt = nullptr;
     float *d_hit_sims = nullptr, *d_hit_sims_alt = nullptr;
-    uint32_t *d_counter = nullptr;  // [0] hits, [1] candidates, [2..] scratch
+    uint32_t *d_counter = nullptr;  // u64 [0] hits, u64 [1] candidates, u32 [8..47] live M-tile counts, then the scan kernels' item queues
+    uint32_t scan_queues_used = 0;  // item queues handed out since the last reset (launch_scan_mfma)
     size_t cand_capacity = 0, cand_alt_capacity = 0;
     uint64_t *d_cand = nullptr, *d_cand_alt = nullptr;
     bool ordered = false;  // the scan path already produced d_matches (MFMA path); order_hits is skipped

@@ -221,8 +221,8 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         FOCR_HIP(c, hipSetDevice(device));
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
-        FOCR_HIP(c, hipMalloc(&c->d_counter, 64 * sizeof(uint32_t)));
-        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        FOCR_HIP(c, hipMalloc(&c->d_counter, COUNTER_BYTES));
+        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, COUNTER_BYTES, c->stream));
         FOCR_HIP(c, hipMalloc((void **)&c->d_res, 8 * sizeof(uint64_t)));
         FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 8 * sizeof(uint64_t), c->stream));
         FOCR_HIP(c, hipHostMalloc((void **)&c->h_res, 8 * sizeof(uint64_t), hipHostMallocDefault));

@@ -19,6 +19,61 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
     if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
 }
 
+// How the waves of a persistent scan kernel get their work.  Items (MT consecutive live M-tiles) are split into one
+// contiguous range per XCD: workgroups b and b + 8 share an XCD and its L2, and neighbouring M-tiles share page rows.  Inside
+// a range the waves TAKE items from a queue (one agent-scope atomic per item, requested one item ahead so that its latency
+// is never waited for) instead of owning a fixed stride: a workgroup needs an empty CU (all of its LDS, all 512 VGPRs of
+// each SIMD), so with other contexts' kernels on the GPU the workgroups of one launch start up to a few 100 us apart, and
+// the time per item varies with the candidates it finds; under a fixed split the launch ends when its unluckiest wave does
+// (BASELINE configs[1], alone on the GPU: 2.20 -> 1.83 ms).  A wave whose range is exhausted goes on with the next XCD's; it
+// stops once it has seen every range exhausted, which every wave reaches after at most n_xc extra requests.
+// queue == nullptr: fixed split (launches past MAX_SCAN_QUEUES in one scan).
+struct ItemTaker {
+    uint32_t *queue;
+    uint32_t n_items, n_xc, per_xc, cur_q, hops, ticket_v, static_item, static_end, stride;
+    int lane;
+    __device__ __forceinline__ void request() {
+        if (queue && lane == 0) ticket_v = __hip_atomic_fetch_add(queue + cur_q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // w: wave index in the workgroup, nw: waves per workgroup
+    __device__ __forceinline__ void init(uint32_t *q, uint32_t items, int lane_, uint32_t w, uint32_t nw) {
+        queue = q;
+        n_items = items;
+        lane = lane_;
+        n_xc = min(8u, gridDim.x);  // small launches have fewer workgroups than XCDs
+        const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
+        const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;  // workgroups in this residue class
+        per_xc = (n_items + n_xc - 1) / n_xc;
+        cur_q = xc;
+        hops = 0;
+        ticket_v = 0;
+        static_item = xc * per_xc + slot * nw + w;
+        static_end = min(n_items, (xc + 1) * per_xc);
+        stride = xc_blocks * nw;
+        request();
+    }
+    // the wave's next item (wave-uniform), or false when there is none left.  Call request() once per item, after the item's
+    // loads have been issued, for the ticket this reads the next time round.
+    __device__ __forceinline__ bool next(uint32_t &item) {
+        if (!queue) {
+            item = static_item;
+            static_item += stride;
+            return item < static_end;
+        }
+        for (;;) {
+            const uint32_t ticket = __builtin_amdgcn_readfirstlane(ticket_v);
+            const uint32_t qb = cur_q * per_xc, qe = min(n_items, qb + per_xc);
+            if (qb < qe && ticket < qe - qb) {
+                item = qb + ticket;
+                return true;
+            }
+            if (++hops >= n_xc) return false;
+            cur_q = cur_q + 1 == n_xc ? 0 : cur_q + 1;
+            request();
+        }
+    }
+};
+
 // K layouts.  One MFMA K-step consumes 64 bytes of a window = four 16-byte k-groups, one per lane group
 // g = lane>>4.  A k-group is built from whole dwords of image rows, so it lands in the operand registers
 // straight from (byte-unaligned) global loads with no byte shuffling:
@@ -74,6 +129,7 @@ struct MfmaLaunch {
     const uint64_t *live_list;   // packed (page << 32 | row << 12 | col) of the M-tiles that have something to scan
     const uint32_t *live_count;  // device-side length of live_list
     uint32_t super_index;
+    uint32_t *queue;      // the launch's item queue (zeroed), or null: static split of the items over the workgroups
     MfmaSegs segs;
     uint32_t Lpitch, Lrows;
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)

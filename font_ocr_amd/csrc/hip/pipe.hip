@@ -155,9 +155,12 @@ int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
             focr_pipe_destroy(p);
             return rc;
         }
-        // several batches in flight: leave one CU of every shader engine (an eighth of the chip) to the small kernels
+        // several batches in flight: the persistent scan kernel takes three quarters of the CUs and leaves the rest to the other
+        // batches' small kernels (statistics, verify, sorts, process_hits) — a scan workgroup fills its CU completely, so they run
+        // nowhere else while a scan is on.  Measured at BASELINE configs[1], 3 batches in flight: 176 / 192 / 208 / 224 / 256 CUs
+        // -> 21.8 / 22.4 / 20.9 / 21.1 / 19.5 Gpx/s (profiles/r02_cu_sweep.log).
         if (n_contexts > 1 && hipGetDeviceProperties(&prop, device) == hipSuccess)
-            focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 8));
+            focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 4));
         L->worker = std::thread(lane_main, L, p);
         p->lanes.push_back(L);
     }

@@ -525,7 +525,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         }
         c->counters[3] = 0;
         c->launches_reset();
-        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, COUNTER_BYTES, c->stream));  // counters + the scan kernels' item queues
+        c->scan_queues_used = 0;
         FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 7 * sizeof(uint64_t), c->stream));
         // Sizes.  Exact mode: the host reads the candidate count after the scan kernels and the hit count after the
         // verify (two waits), so every later phase runs on exact sizes.  Estimated mode (ctx.hip: same setup as the
@@ -702,6 +703,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
                 const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
+                if (c->scan_queues_used < MAX_SCAN_QUEUES) L.queue = c->d_counter + COUNTER_WORDS + (size_t)(c->scan_queues_used++) * QUEUE_XCDS * QUEUE_STRIDE;
                 if (two[si] == 1) {
                     A3.norms = c->d_norms + norm_off[si];
                     A3.norm_stride = plane;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -50,18 +50,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 
     const uint32_t total_mt = *live_count;  // live 16-window M-tiles of this pass (blank paper is skipped)
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    // XCD-aware work split: workgroups b and b + 8 share an XCD (its own L2), so the 8 residue classes of
-    // blockIdx.x each take one contiguous eighth of the work list (= their own pages and image rows, which the
-    // 15 window rows touching them then find in that L2) and stride through it by the waves of the class.
-    const uint32_t n_xc = min(8u, gridDim.x);               // small launches have fewer classes than XCDs
-    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
-    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;  // workgroups in this residue class
-    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
-    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
-    const uint32_t stride = xc_blocks * NW;
+    ItemTaker take;  // XCD-aware split of the work list + item queue (mfma_common.h)
+    take.init(queue, n_items, lane, (uint32_t)w, NW);
 
     v4i afrag[MT][KSTEPS];
-    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
+    for (uint32_t item; take.next(item);) {
         // coordinates of the item's M-tiles (wave-uniform, scalar loads)
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
@@ -115,6 +108,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;
             }
         }
+        take.request();  // the next item's ticket
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {  // M-tiles past the end of the enumeration never flag
             const int keep = pv[mt] ? -1 : 0;
@@ -212,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const Mfma3Args P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -228,12 +222,6 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 
     const uint32_t total_mt = *live_count;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    const uint32_t n_xc = min(8u, gridDim.x);
-    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
-    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;
-    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
-    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
-    const uint32_t stride = xc_blocks * NW;
     float kq_of_value[NV];  // threshold scale per norm value (= per size class of the super-class)
 #pragma unroll
     for (int v = 0; v < NV; v++) {
@@ -243,8 +231,10 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
             if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) kq_of_value[v] = P.kq[sg];
     }
 
+    ItemTaker take;
+    take.init(queue, n_items, lane, (uint32_t)w, NW);
     v4i afrag[MT][KSTEPS];
-    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
+    for (uint32_t item; take.next(item);) {
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
         bool pv[MT];
@@ -293,6 +283,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): the quantised templates sum to zero
             }
         }
+        take.request();  // the next item's ticket
         // C-in of the lane's own window per size class: -(floor(kq * norm_c) - 2) (scan_mfma.hip: conservative for
         // |L| < 4e6), -REJECT where the class never emits (the statistics kernel flags that in the sign) or past the enumeration
         int cin[MT][NV];
@@ -388,7 +379,7 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, un
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
-                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand);
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue);
     c->launch_end();
 }
 
@@ -428,7 +419,7 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
-                       (unsigned long long)c->ub_cand);
+                       (unsigned long long)c->ub_cand, L.queue);
     c->launch_end();
 }
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, const v4i *__restrict__ basis_g,
     const v4i *__restrict__ gbank_g, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows, const Mfma3Args P,
     const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem3[];
     v4i *bank = reinterpret_cast<v4i *>(smem3);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -100,12 +100,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
 
     const uint32_t total_mt = *live_count;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    const uint32_t n_xc = min(8u, gridDim.x);
-    const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
-    const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;
-    const uint32_t per_xc = (n_items + n_xc - 1) / n_xc;
-    const uint32_t item_end = min(n_items, (xc + 1) * per_xc);
-    const uint32_t stride = xc_blocks * NW;
+    ItemTaker take;  // XCD-aware split of the work list + item queue (mfma_common.h)
+    take.init(queue, n_items, lane, (uint32_t)w, NW);
     const uint32_t n_extras = 2 + P.n_cls;
     // segments (size classes) of the launch: at most LR_MAX_CLASSES, boundaries and norm-value indices as scalars
     const uint32_t seg_end0 = segs.n > 0 ? segs.s[0].tile_end : 0xffffffffu, seg_end1 = segs.n > 1 ? segs.s[1].tile_end : 0xffffffffu;
@@ -123,7 +119,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
 #ifdef FOCR_MFMA3_PROF
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
-    for (uint32_t item = xc * per_xc + slot * NW + w; item < item_end; item += stride) {
+#ifdef FOCR_MFMA3_PROF
+    unsigned long long prof_items = 0;
+#endif
+    for (uint32_t item; take.next(item);) {
+#ifdef FOCR_MFMA3_PROF
+        prof_items++;
+#endif
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
         bool pv[MT];
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): every int8 operand row sums to zero
             }
         }
+        take.request();  // the next item's ticket
         PROF_STAMP(0)
         // ---- stage 1: y = basis x windows^T ----
         v4i y[MT][LR_BASIS_TILES];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
     if (lane == 0)
     {
         for (int i = 0; i < 6; i++) atomicAdd(&focr_prof[i], prof_acc[i]);
-        atomicAdd(&focr_prof[6], (unsigned long long)((item_end > xc * per_xc + slot * NW + w) ? (item_end - (xc * per_xc + slot * NW + w) + stride - 1) / stride : 0));
+        atomicAdd(&focr_prof[6], prof_items);
     }
 #endif
 }
@@ -393,7 +396,7 @@ static void launch_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, con
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                        (uint32_t)c->rows_alloc, L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset),
                        reinterpret_cast<const v4i *>(basis), reinterpret_cast<const v4i *>(gbank), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
-                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand);
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue);
     c->launch_end();
 }
 
