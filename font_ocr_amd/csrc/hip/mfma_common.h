@@ -27,39 +27,28 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
 // the time per item varies with the candidates it finds; under a fixed split the launch ends when its unluckiest wave does
 // (BASELINE configs[1], alone on the GPU: 2.20 -> 1.83 ms).  A wave whose range is exhausted goes on with the next XCD's; it
 // stops once it has seen every range exhausted, which every wave reaches after at most n_xc extra requests.
-// queue == nullptr: fixed split (launches past MAX_SCAN_QUEUES in one scan).
+// The queue (QUEUE_XCDS counters, QUEUE_STRIDE dwords apart) is zeroed by the memset that opens every scan (launch_scan_mfma).
 struct ItemTaker {
     uint32_t *queue;
-    uint32_t n_items, n_xc, per_xc, cur_q, hops, ticket_v, static_item, static_end, stride;
+    uint32_t n_items, n_xc, per_xc, cur_q, hops, ticket_v;
     int lane;
     __device__ __forceinline__ void request() {
-        if (queue && lane == 0) ticket_v = __hip_atomic_fetch_add(queue + cur_q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) ticket_v = __hip_atomic_fetch_add(queue + cur_q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // w: wave index in the workgroup, nw: waves per workgroup
-    __device__ __forceinline__ void init(uint32_t *q, uint32_t items, int lane_, uint32_t w, uint32_t nw) {
+    __device__ __forceinline__ void init(uint32_t *q, uint32_t items, int lane_) {
         queue = q;
         n_items = items;
         lane = lane_;
-        n_xc = min(8u, gridDim.x);  // small launches have fewer workgroups than XCDs
-        const uint32_t xc = blockIdx.x % n_xc, slot = blockIdx.x / n_xc;
-        const uint32_t xc_blocks = (gridDim.x - xc + n_xc - 1) / n_xc;  // workgroups in this residue class
+        n_xc = min(QUEUE_XCDS, gridDim.x);  // small launches have fewer workgroups than XCDs
         per_xc = (n_items + n_xc - 1) / n_xc;
-        cur_q = xc;
+        cur_q = blockIdx.x % n_xc;
         hops = 0;
         ticket_v = 0;
-        static_item = xc * per_xc + slot * nw + w;
-        static_end = min(n_items, (xc + 1) * per_xc);
-        stride = xc_blocks * nw;
         request();
     }
     // the wave's next item (wave-uniform), or false when there is none left.  Call request() once per item, after the item's
     // loads have been issued, for the ticket this reads the next time round.
     __device__ __forceinline__ bool next(uint32_t &item) {
-        if (!queue) {
-            item = static_item;
-            static_item += stride;
-            return item < static_end;
-        }
         for (;;) {
             const uint32_t ticket = __builtin_amdgcn_readfirstlane(ticket_v);
             const uint32_t qb = cur_q * per_xc, qe = min(n_items, qb + per_xc);
@@ -129,7 +118,7 @@ struct MfmaLaunch {
     const uint64_t *live_list;   // packed (page << 32 | row << 12 | col) of the M-tiles that have something to scan
     const uint32_t *live_count;  // device-side length of live_list
     uint32_t super_index;
-    uint32_t *queue;      // the launch's item queue (zeroed), or null: static split of the items over the workgroups
+    uint32_t *queue;      // the launch's item queue (zeroed at the start of the scan)
     MfmaSegs segs;
     uint32_t Lpitch, Lrows;
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)

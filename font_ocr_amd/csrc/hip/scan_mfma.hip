@@ -703,7 +703,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
                 const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
-                if (c->scan_queues_used < MAX_SCAN_QUEUES) L.queue = c->d_counter + COUNTER_WORDS + (size_t)(c->scan_queues_used++) * QUEUE_XCDS * QUEUE_STRIDE;
+                if (c->scan_queues_used >= MAX_SCAN_QUEUES) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many scan passes for one call (bank too large)");
+                L.queue = c->d_counter + COUNTER_WORDS + (size_t)(c->scan_queues_used++) * QUEUE_XCDS * QUEUE_STRIDE;
                 if (two[si] == 1) {
                     A3.norms = c->d_norms + norm_off[si];
                     A3.norm_stride = plane;

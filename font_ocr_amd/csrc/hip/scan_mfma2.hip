@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint32_t total_mt = *live_count;  // live 16-window M-tiles of this pass (blank paper is skipped)
     const uint32_t n_items = (total_mt + MT - 1) / MT;
     ItemTaker take;  // XCD-aware split of the work list + item queue (mfma_common.h)
-    take.init(queue, n_items, lane, (uint32_t)w, NW);
+    take.init(queue, n_items, lane);
 
     v4i afrag[MT][KSTEPS];
     for (uint32_t item; take.next(item);) {
@@ -201,6 +201,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 #ifndef FOCR_V2S_NW
 #define FOCR_V2S_NW 16  // waves per workgroup (one workgroup per CU); experiment builds: make hip EXTRA=-DFOCR_V2S_NW=12
 #endif
+#ifdef FOCR_V2S_VARIANTS
+// experiment builds only: timing of the kernel with parts of the candidate path cut out (results are wrong then)
+__device__ int focr_v2s_variant;
+extern "C" int focr_debug_v2s_variant(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(focr_v2s_variant), &v, sizeof v) == hipSuccess ? 0 : 1; }
+#endif
+#ifdef FOCR_V2S_PROF
+// experiment builds only (make hip EXTRA=-DFOCR_V2S_PROF; tools/prof2s.py): per-phase wave time (s_memtime ticks), summed over all waves
+__device__ unsigned long long focr_prof2[8];
+#define PROF2(i)                                                      \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        prof_acc[i] += now_ - prof_t;                                 \
+        prof_t = now_;                                                \
+    }
+#else
+#define PROF2(i)
+#endif
 template <int KSTEPS, int RPG, int MT, int NW, int NV>
 __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
@@ -232,32 +249,59 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     }
 
     ItemTaker take;
-    take.init(queue, n_items, lane, (uint32_t)w, NW);
+    take.init(queue, n_items, lane);
     v4i afrag[MT][KSTEPS];
+#ifdef FOCR_V2S_VARIANTS
+    const int variant = __builtin_amdgcn_readfirstlane(focr_v2s_variant);
+#endif
+#ifdef FOCR_V2S_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t item; take.next(item);) {
+        PROF2(5)  // waiting for the ticket
+#ifdef FOCR_V2S_PROF
+        prof_acc[7]++;
+#endif
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
         bool pv[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             pv[mt] = m0 + mt < total_mt;
+#ifdef FOCR_V2S_VARIANTS
+            const uint64_t e = (variant & 16) ? (uint64_t)((m0 + mt) % 40) | ((uint64_t)(((m0 + mt) / 40) % 590) << 12) | ((uint64_t)(((m0 + mt) / 23600) & 127) << 32)
+                                              : live_list[pv[mt] ? m0 + mt : total_mt - 1];
+#else
             const uint64_t e = live_list[pv[mt] ? m0 + mt : total_mt - 1];
+#endif
             px[mt] = 16 * (uint32_t)(e & 0xfff);
             py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
             pp[mt] = (uint32_t)(e >> 32);
         }
         float nrm[MT][NV];  // norms of the lane's own window px + r, one per size class
+#ifdef FOCR_V2S_VARIANTS
+        if (variant & 8) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) nrm[mt][v] = 900.f + (float)lane;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++) afrag[mt][ks] = v4i{(int)px[mt] * 77 + lane, (int)py[mt] * 1315423911 + lane * 31, (int)pp[mt] + lane * 7, lane * 0x01010101};
+            }
+        } else {
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const uint16_t *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
 #pragma unroll
             for (int v = 0; v < NV; v++) nrm[mt][v] = (float)__builtin_bit_cast(_Float16, np[(size_t)v * P.norm_stride]);  // f16, a lower bound
         }
+        // K-step-major issue order: the N-tile loop's first MFMAs need K-step 0 of all M-tiles
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
+        for (int ks = 0; ks < KSTEPS; ks++) {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
+            for (int mt = 0; mt < MT; mt++) {
+                const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
                 v4i a;
                 if (RPG == LAYOUT_W16) {
                     a = *reinterpret_cast<const v4i_u *>(base + (size_t)(4 * ks + g) * pitch);
@@ -283,7 +327,15 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): the quantised templates sum to zero
             }
         }
+#ifdef FOCR_V2S_VARIANTS
+        }
+#endif
         take.request();  // the next item's ticket
+        PROF2(0)
+#ifdef FOCR_V2S_PROF
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the item's loads (the ticket may stay outstanding)
+        PROF2(1)
+#endif
         // C-in of the lane's own window per size class: -(floor(kq * norm_c) - 2) (scan_mfma.hip: conservative for
         // |L| < 4e6), -REJECT where the class never emits (the statistics kernel flags that in the sign) or past the enumeration
         int cin[MT][NV];
@@ -328,7 +380,14 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                     m = max(max(m, acc[mt][0]), acc[mt][1]);
                     m = max(max(m, acc[mt][2]), acc[mt][3]);
                 }
+#ifdef FOCR_V2S_VARIANTS
+                if (variant & 1) continue;
+#endif
                 if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
+                    PROF2(2)
+#ifdef FOCR_V2S_VARIANTS
+                    if (variant & 2) { asm volatile("s_nop 0"); continue; }
+#endif
                     // The candidate path costs 0.33 of the kernel's 2.3 ms at C2 (3.8 M candidates; threshold sweep in
                     // DESIGN.md), so it is kept short: ONE LDS read per visit for the lane's four template ids (lane (r, g),
                     // register i: template 4g + i of the tile, window px + r; ~0 = dead / padding, never emits), one ballot per
@@ -338,6 +397,9 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                     for (int mt = 0; mt < MT; mt++) {
                         const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
                         if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
+#ifdef FOCR_V2S_VARIANTS
+                        if (variant & 4) { asm volatile("s_nop 0"); continue; }
+#endif
                         uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
                         asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
                         const uint64_t kbase = fmt.pack(page_base + pg, yy, xx, 0) + ((uint64_t)r << fmt.bt);  // x = px + r < 2^bx: no carry into y
@@ -348,19 +410,33 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                             if (!okmask) continue;  // wave-uniform
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
                             if (wcount + cnt > WBUF) {
+                                PROF2(3)
                                 flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
                                 wcount = 0;
+                                PROF2(4)
+#ifdef FOCR_V2S_PROF
+                                prof_acc[6] += 1ull << 32;  // flushes in the high half, visits in the low half
+#endif
                             }
                             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
                             if (ok) wbuf[wcount + pos] = kbase + (uint32_t)tg4[i];
                             wcount += cnt;
                         }
                     }
+                    PROF2(3)
+#ifdef FOCR_V2S_PROF
+                    prof_acc[6]++;
+#endif
                 }
             }
         }
+        PROF2(2)
     }
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+#ifdef FOCR_V2S_PROF
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&focr_prof2[i], prof_acc[i]);
+#endif
 }
 
 template <int KSTEPS, int RPG, int NV>
@@ -382,6 +458,17 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, un
                        c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue);
     c->launch_end();
 }
+
+#ifdef FOCR_V2S_PROF
+extern "C" int focr_debug_prof2(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(focr_prof2), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(focr_prof2), z, sizeof z);
+    }
+    return 0;
+}
+#endif
 
 int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
     const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);

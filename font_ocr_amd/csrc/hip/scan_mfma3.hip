@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
     const uint32_t total_mt = *live_count;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
     ItemTaker take;  // XCD-aware split of the work list + item queue (mfma_common.h)
-    take.init(queue, n_items, lane, (uint32_t)w, NW);
+    take.init(queue, n_items, lane);
     const uint32_t n_extras = 2 + P.n_cls;
     // segments (size classes) of the launch: at most LR_MAX_CLASSES, boundaries and norm-value indices as scalars
     const uint32_t seg_end0 = segs.n > 0 ? segs.s[0].tile_end : 0xffffffffu, seg_end1 = segs.n > 1 ? segs.s[1].tile_end : 0xffffffffu;
