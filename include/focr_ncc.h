@@ -243,8 +243,8 @@ int focr_ctx_set_size_estimates(focr_ctx_t *ctx, int on);
  * par_iter over pages): n contexts on one device, one worker thread each;
  * batches are handed out round-robin and complete in submission order.  One
  * batch's small kernels then overlap another's MFMA scan (DESIGN.md section 5:
- * 15.7 -> 22 Gpx/s at configs[1] with three contexts).  With more than one
- * context the scan kernel of each is capped to 7/8 of the CUs.
+ * 17.8 -> 22.6 Gpx/s at configs[1] with three contexts).  With more than one
+ * context the scan kernel of each is capped to 3/4 of the CUs.
  *
  *   focr_pipe_create(dev, 3, &p); focr_pipe_bank_upload(p, ...);
  *   for each batch b:   if (b >= 3) { wait(t[b-3], &ctx); read results from ctx; release(t[b-3]); }
