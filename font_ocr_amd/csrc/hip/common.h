@@ -115,7 +115,7 @@ struct focr_ctx {
     // ---- result sizes (ctx.hip: finish_results) ----
     // Every phase after the scan kernel takes its element count from device memory; the host only supplies upper bounds for
     // grids and buffers.  Exact mode reads the counts between the phases (as round 1 did); estimated mode (same bank,
-    // geometry, threshold, cap as the previous scan) bounds them by the previous scan's counts + 20 %, launches everything
+    // geometry, threshold, cap as the previous scan) bounds them by the previous scan's counts + a margin (4 .. 20 %), launches everything
     // without waiting, and reads all sizes once at the end; a count above its bound redoes the batch in exact mode.
     uint64_t *d_res = nullptr;   // [0] candidates [1] hits [2] matches [3] lines << 32 | chars [4] overflow flag [7] scratch count
     uint64_t *h_res = nullptr;   // pinned copy
@@ -125,6 +125,10 @@ struct focr_ctx {
     uint64_t n_hits_raw_u64 = 0;
     bool sizes_pending = false, post_pending = false, estimated = false, estimates_enabled = true;
     size_t est_cand = 0, est_hits = 0, ub_cand = 0;
+    // how much the counts of consecutive scans of one setup have differed lately (relative; decays by a quarter per scan):
+    // the next scan's bounds are the last counts + 3 x this, between 4 % and 20 % (finish_results)
+    double est_var = 0.0667;
+    uint64_t est_last_cand = 0, est_last_hits = 0;
     uint64_t est_sig = 0, bank_gen = 0, counters_redone = 0;
     float scan_thr = 0.f, post_anchor = 0.f;
     int scan_mode = 0;

@@ -648,6 +648,8 @@ int finish_results(focr_ctx *c) {
             c->post_pending = false;
             c->estimated = false;
             c->est_cand = c->est_hits = 0;
+            c->est_var = 0.0667;  // back to the 20 % margin
+            c->est_last_cand = c->est_last_hits = 0;
             c->counters_redone++;
             int rc = scan_now(c);
             if (rc) return rc;
@@ -668,9 +670,18 @@ int finish_results(focr_ctx *c) {
                 c->counters[3] += li.issued_macs;
             }
             c->launches_collect();
-            // bounds for the next scan of the same setup: this scan's counts + 20 %
-            c->est_cand = (size_t)n_cand + (size_t)n_cand / 5 + 32768;
-            c->est_hits = (size_t)n_hits + (size_t)n_hits / 5 + 32768;
+            // bounds for the next scan of the same setup: this scan's counts + a margin that follows how much the counts have
+            // been moving (20 % after the first scan of a setup; 4 % once consecutive batches agree to ~1 %): every element of
+            // margin is sorted, scanned and stepped over by all the later phases
+            if (c->est_last_cand) {
+                const auto rel = [](uint64_t a, uint64_t b) { return (double)(a > b ? a - b : b - a) / (double)std::max<uint64_t>(std::min(a, b), 1); };
+                c->est_var = std::max(c->est_var * 0.75, std::max(rel(n_cand, c->est_last_cand), rel(n_hits, c->est_last_hits)));
+            }
+            c->est_last_cand = n_cand;
+            c->est_last_hits = n_hits;
+            const double margin = std::min(0.2, std::max(0.04, 3.0 * c->est_var));
+            c->est_cand = (size_t)n_cand + (size_t)((double)n_cand * margin) + 8192;
+            c->est_hits = (size_t)n_hits + (size_t)((double)n_hits * margin) + 8192;
         }
         c->counters[1] = n_hits;
         c->n_hits = c->n_hits_raw = (size_t)n_hits;
@@ -724,7 +735,11 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     for (uint64_t v : {(uint64_t)c->bank_gen, (uint64_t)c->n_pages, (uint64_t)c->r_w, (uint64_t)c->r_h, (uint64_t)tb, (uint64_t)cap, (uint64_t)mode,
                        (uint64_t)c->prefilter})
         sig = (sig ^ v) * 1099511628211ull;
-    if (sig != c->est_sig) c->est_cand = c->est_hits = 0;
+    if (sig != c->est_sig) {
+        c->est_cand = c->est_hits = 0;
+        c->est_var = 0.0667;
+        c->est_last_cand = c->est_last_hits = 0;
+    }
     c->est_sig = sig;
     c->estimated = c->estimates_enabled && mode == FOCR_SCAN_MFMA && !c->force_split && c->est_cand != 0;
     return scan_now(c);

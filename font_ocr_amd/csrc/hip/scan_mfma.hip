@@ -530,7 +530,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 7 * sizeof(uint64_t), c->stream));
         // Sizes.  Exact mode: the host reads the candidate count after the scan kernels and the hit count after the
         // verify (two waits), so every later phase runs on exact sizes.  Estimated mode (ctx.hip: same setup as the
-        // previous scan): the counts stay on the device, grids and buffers take the previous counts + 20 % as bounds,
+        // previous scan): the counts stay on the device, grids and buffers take the previous counts + a margin (4 .. 20 %, ctx.hip) as bounds,
         // unused candidate slots hold the largest key so that the sort leaves them at the end; nothing waits.
         c->ub_cand = c->estimated ? std::min(c->est_cand, c->cand_capacity) : c->cand_capacity;
         if (c->estimated) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));

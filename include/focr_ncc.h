@@ -232,7 +232,7 @@ int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
 
 /* Result sizes.  Every phase behind the scan kernel takes its element count from device memory.  A scan of the same
  * setup as the context's previous one (same bank, batch geometry, threshold, cap) bounds its buffers by the previous
- * scan's counts + 20 %, queues all phases (and a following focr_process_hits) without a host wait, and the first call
+ * scan's counts + a margin (4 .. 20 %, following how much consecutive counts differ), queues all phases (and a following focr_process_hits) without a host wait, and the first call
  * that needs a size (any getter, focr_sync, focr_pipe_wait) waits once; a count above its bound makes that call redo the
  * batch with exact sizes, so results never depend on the estimate.  on = 0 restores round 1's behaviour (the host
  * reads the candidate and hit counts between the phases of every scan).  Default: on. */

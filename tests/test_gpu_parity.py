@@ -756,7 +756,7 @@ def test_rust_scan_mode_vs_oracle(scanner, bank_x2, thr):
 
 @pytest.mark.parametrize("mode", MODES[1:])
 def test_size_estimates_and_redo_on_overflow(bank_x2, mode):
-    """Repeat scans of one setup run on the previous scan's counts + 20 % without host waits (focr_ctx_set_size_estimates);
+    """Repeat scans of one setup run on the previous scan's counts + a margin (4 .. 20 %) without host waits (focr_ctx_set_size_estimates);
     a batch with far more hits than the previous one must overflow those bounds, be redone with exact sizes, and still give
     the reference lists and process_hits output — also when process_hits was already queued behind the scan."""
     bank = bank_x2.subset(list(range(33, 80)) + list(range(95 + 33, 95 + 80)))
