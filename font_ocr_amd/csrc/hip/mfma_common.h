@@ -68,12 +68,12 @@ struct ItemTaker {
 // straight from (byte-unaligned) global loads with no byte shuffling:
 //   LAYOUT_W16 (n_w 13..16): group q = row q, columns 0..15.                 K-step ks, lane group g: q = 4ks+g
 //   LAYOUT_W8  (n_w <= 8)  : group q = rows 2q, 2q+1, columns 0..7 each.     q = 4ks+g
-//   LAYOUT_W12 (n_w 9..12) : rows are 12 bytes; a quad of rows (4m..4m+3) fills exactly three groups
-//        p=0: row 4m   cols 0..11 | row 4m+1 cols 0..3
-//        p=1: row 4m+1 cols 4..11 | row 4m+2 cols 0..7
-//        p=2: row 4m+2 cols 8..11 | row 4m+3 cols 0..11
-//     and the (K-step, lane group) of quad m, part p is ks = 3*(m/4) + p, g = m%4, so that every lane of a
-//     K-step issues the same load widths.  16 rows -> 3 K-steps (192 bytes) instead of 4.
+//   LAYOUT_W12 (n_w 9..12) : rows are 12 bytes = 3 dwords; a quad of rows (4m..4m+3) fills exactly three groups, one per
+//     dword COLUMN c = 0, 1, 2: group (m, c) = dword c (columns 4c..4c+3) of rows 4m, 4m+1, 4m+2, 4m+3.
+//     (K-step, lane group) of group (m, c): ks = 3*(m/4) + c, g = m%4 — a K-step is a 4-column strip of 16 rows, so the
+//     last K-step of a 16-row block holds nothing but zeros for templates of n_w <= 8 and the kernels skip its MFMAs for
+//     such a size class (Mfma3Args::seg_full).  A lane loads its 4 rows once (12 contiguous bytes each) whatever the order.
+//     16 rows -> 3 K-steps (192 bytes) instead of 4.
 // Template bytes outside n_w x n_h are zero, so the extra image bytes the A side picks up do not matter.
 enum { LAYOUT_W16 = 1, LAYOUT_W8 = 2, LAYOUT_W12 = 3 };
 
@@ -85,13 +85,8 @@ __host__ __device__ inline void kgroup_of(uint32_t layout, uint32_t j, uint32_t 
         const uint32_t q = j / 2;
         *ks = q / 4, *g = q % 4, *byte = 8 * (j % 2) + x;
     } else {
-        const uint32_t m = j / 4, rr = j % 4;
-        uint32_t p, b;
-        if (rr == 0) p = 0, b = x;                          // row 4m: all 12 columns in part 0
-        else if (rr == 1) { if (x < 4) p = 0, b = 12 + x; else p = 1, b = x - 4; }
-        else if (rr == 2) { if (x < 8) p = 1, b = 8 + x; else p = 2, b = x - 8; }
-        else p = 2, b = 4 + x;
-        *ks = 3 * (m / 4) + p, *g = m % 4, *byte = b;
+        const uint32_t m = j / 4;
+        *ks = 3 * (m / 4) + x / 4, *g = m % 4, *byte = 4 * (j % 4) + x % 4;
     }
 }
 
@@ -156,6 +151,7 @@ struct Mfma3Args {
     uint32_t theta_add;      // 0xffff if thr_lo < 0 (bf16 rounding of theta towards -inf), else 0
     float kq[MAX_SEGS];      // per segment of the launch: L = floor(kq * norm_c) - 2, the exact-taps stage's threshold
     uint32_t seg_value[MAX_SEGS];  // per segment: the norm value of its class
+    uint32_t seg_full[MAX_SEGS];   // per segment: 0 if the class's templates are all zero in the last K-step (LAYOUT_W12, n_w <= 8)
 };
 
 // scan_mfma3.hip

@@ -685,6 +685,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                         kq = std::nextafterf(kq, -INFINITY);
                         A3.kq[L.segs.n] = std::isfinite(kq) ? kq : -3.0e38f;
                         A3.seg_value[L.segs.n] = (uint32_t)i;
+                        A3.seg_full[L.segs.n] = (su.layout == LAYOUT_W12 && sc.n_w <= 8) ? 0u : 1u;  // mfma_common.h: K layouts
                     }
                     MfmaSeg &sg = L.segs.s[L.segs.n++];
                     sg.negL = c->d_L + su.classes[i] * L_per_class;

@@ -89,20 +89,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                     const uint8_t *p0 = base + (size_t)(2 * (4 * ks + g)) * pitch;
                     const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
                     a = v4i{lo[0], lo[1], hi[0], hi[1]};
-                } else {  // LAYOUT_W12: row quad m = 4*(ks/3)+g, part p = ks%3 (compile-time)
-                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
-                    if (ks % 3 == 0) {
-                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
-                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
-                        a = v4i{t[0], t[1], t[2], u};
-                    } else if (ks % 3 == 1) {
-                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
-                        a = v4i{t[0], t[1], u[0], u[1]};
-                    } else {
-                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
-                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
-                        a = v4i{t, u[0], u[1], u[2]};
-                    }
+                } else {
+                    // LAYOUT_W12: K-step 3*(m/4) + c = dword column c of the rows of quad m = 4*(ks/3)+g (mfma_common.h)
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch + 4 * (ks % 3);
+                    a = v4i{*reinterpret_cast<const int_u *>(q0), *reinterpret_cast<const int_u *>(q0 + pitch),
+                            *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch), *reinterpret_cast<const int_u *>(q0 + 3 * (size_t)pitch)};
                 }
                 // u8 -> i8 (a - 128): the quantised templates sum to zero, so the bias cancels exactly
                 afrag[mt][ks] = a ^ (int)0x80808080;
@@ -310,19 +301,10 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                     const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
                     a = v4i{lo[0], lo[1], hi[0], hi[1]};
                 } else {
-                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
-                    if (ks % 3 == 0) {
-                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
-                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
-                        a = v4i{t[0], t[1], t[2], u};
-                    } else if (ks % 3 == 1) {
-                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
-                        a = v4i{t[0], t[1], u[0], u[1]};
-                    } else {
-                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
-                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
-                        a = v4i{t, u[0], u[1], u[2]};
-                    }
+                    // LAYOUT_W12: K-step 3*(m/4) + c = dword column c of the rows of quad m = 4*(ks/3)+g (mfma_common.h)
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch + 4 * (ks % 3);
+                    a = v4i{*reinterpret_cast<const int_u *>(q0), *reinterpret_cast<const int_u *>(q0 + pitch),
+                            *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch), *reinterpret_cast<const int_u *>(q0 + 3 * (size_t)pitch)};
                 }
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): the quantised templates sum to zero
             }
@@ -354,6 +336,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         uint32_t nt = 0;
         for (uint32_t sgi = 0; sgi < segs.n; sgi++) {  // one segment = the N-tiles of one size class
             const uint32_t seg_end = segs.s[sgi].tile_end, sv = P.seg_value[sgi];
+            const bool full = P.seg_full[sgi] != 0;  // false: the class's templates are all zero in the last K-step (12-byte rows, n_w <= 8)
             int ci[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -368,9 +351,11 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                 const uint32_t nxt = nt + 1 < n_tiles16 ? nt + 1 : nt;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ks++) {
+                    if (RPG != LAYOUT_W12 || ks + 1 < KSTEPS || full) {  // wave-uniform
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
-                        acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[ks], afrag[mt][ks], acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; mt++)
+                            acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[ks], afrag[mt][ks], acc[mt], 0, 0, 0);
+                    }
                     bf[ks] = bank[(nxt * KSTEPS + ks) * 64 + lane];
                     __builtin_amdgcn_sched_barrier(0);  // pin the re-load here (see scan_mfma2_kernel)
                 }
@@ -449,7 +434,9 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, un
     unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
     auto kern = scan_mfma2s_kernel<KSTEPS, RPG, MT, NW, NV>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const uint64_t issued = 16 * (uint64_t)n_tiles16 * 16 * KSTEPS * 64;  // per live M-tile; scaled by the live count after the scan
+    uint64_t ksteps_issued = 0;  // K-steps per live M-tile: the last one is skipped for classes that are all zero there
+    for (uint32_t i = 0, t = 0; i < L.segs.n; t = L.segs.s[i].tile_end, i++) ksteps_issued += (uint64_t)(L.segs.s[i].tile_end - t) * (KSTEPS - (A3.seg_full[i] ? 0 : 1));
+    const uint64_t issued = 16 * ksteps_issued * 16 * 64;  // per live M-tile; scaled by the live count after the scan
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2s_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);

@@ -160,19 +160,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma3_kernel(
                     const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
                     a = v4i{lo[0], lo[1], hi[0], hi[1]};
                 } else {
-                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch;
-                    if (ks % 3 == 0) {
-                        const v3i t = *reinterpret_cast<const v3i_u *>(q0);
-                        const int u = *reinterpret_cast<const int_u *>(q0 + pitch);
-                        a = v4i{t[0], t[1], t[2], u};
-                    } else if (ks % 3 == 1) {
-                        const v2i t = *reinterpret_cast<const v2i_u *>(q0 + pitch + 4), u = *reinterpret_cast<const v2i_u *>(q0 + 2 * (size_t)pitch);
-                        a = v4i{t[0], t[1], u[0], u[1]};
-                    } else {
-                        const int t = *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch + 8);
-                        const v3i u = *reinterpret_cast<const v3i_u *>(q0 + 3 * (size_t)pitch);
-                        a = v4i{t, u[0], u[1], u[2]};
-                    }
+                    // LAYOUT_W12: K-step 3*(m/4) + c = dword column c of the rows of quad m = 4*(ks/3)+g (mfma_common.h)
+                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch + 4 * (ks % 3);
+                    a = v4i{*reinterpret_cast<const int_u *>(q0), *reinterpret_cast<const int_u *>(q0 + pitch),
+                            *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch), *reinterpret_cast<const int_u *>(q0 + 3 * (size_t)pitch)};
                 }
                 afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): every int8 operand row sums to zero
             }
