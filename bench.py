@@ -315,10 +315,16 @@ def main():
         step(k)
     fence()
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_s:
+    go = args.settle_s > 0
+    while go:
         for k in range(2 * n_ctx):
             step(k)
         fence()
+        go = time.perf_counter() - t_settle < args.settle_s
+        if use_dist and world > 1:  # every rank must run the same number of rounds: each one ends in collectives (fence)
+            flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go = bool(flag.item())
     timed = True
     t0 = time.perf_counter()
     for k in range(args.steps):
