@@ -832,3 +832,17 @@ def test_compat_symbols_in_the_reference_call_pattern(bank_x2):
     if O.have_ref():
         assert t_gpu < t_ref, (t_gpu, t_ref)
     print(f"380 drop-in calls: {t_gpu * 1e3:.0f} ms on the device path, {t_ref * 1e3:.0f} ms with the reference kernel on one core")
+
+
+def test_pipeline_soak_mfma_equals_direct():
+    """tools/stress_pipeline.py: 60 different batches (sizes, geometries, thresholds, blank pages) through the three-lane
+    pipeline — MFMA prefilter with item queues, estimated result sizes, scans taking turns — each compared with the direct
+    scan of the same pages on another context: matches, counts and lines must be identical."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_pipeline.py"), "--batches", "60", "--pages", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
