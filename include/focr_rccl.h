@@ -28,7 +28,8 @@ const char *focr_gather_last_error(void);
  * focr_pipe_submit with focr_total_chars * sizeof(focr_hit_t)) -> one contiguous buffer d_dst on devices[0], in rank order
  * (= page order when ranks hold contiguous page blocks).  The sizes are known to the single host process, so no size
  * exchange is needed: one grouped ncclSend / ncclRecv per rank.  Blocks until the data is in d_dst.  dst_bytes must be >=
- * the sum of bytes[]. */
+ * the sum of bytes[].  The gather runs on its own streams: the sources must be complete when it is called (they are once
+ * the getter that returned the size — focr_total_chars, focr_pipe_wait — has returned). */
 int focr_gather_bytes(focr_gather_t *g, const void *const *d_src, const size_t *bytes, void *d_dst, size_t dst_bytes);
 
 #ifdef __cplusplus
