@@ -128,6 +128,19 @@ HIP_SYMBOLS = {
     "focr_get_lines_into": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "focr_pipe_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "focr_pipe_release": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "focr_fleet_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint, C.c_uint, C.POINTER(C.c_void_p)]),
+    "focr_fleet_destroy": (None, [C.c_void_p]),
+    "focr_fleet_devices": (C.c_uint, [C.c_void_p]),
+    "focr_fleet_lanes": (C.c_uint, [C.c_void_p]),
+    "focr_fleet_pipe": (C.c_void_p, [C.c_void_p, C.c_uint]),
+    "focr_fleet_device_of": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "focr_fleet_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "focr_fleet_set_fetch": (C.c_int, [C.c_void_p, C.c_int]),
+    "focr_fleet_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_uint32,
+                                    C.c_int, C.c_int, C.c_float, C.c_int32, C.POINTER(C.c_uint64)]),
+    "focr_fleet_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "focr_fleet_host_results": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "focr_fleet_release": (C.c_int, [C.c_void_p, C.c_uint64]),
     "focr_last_launches": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_debug_rnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

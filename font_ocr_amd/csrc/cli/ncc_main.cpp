@@ -412,21 +412,16 @@ int main(int argc, char **argv) {
     n_dev = std::min<size_t>({(size_t)std::max(0, focr_device_count()), dev_cap, n_batches});
     if (n_dev == 0) fatal(std::string("no usable GPU: ") + focr_last_error_global());
     n_lanes = std::min(n_lanes, (n_batches + n_dev - 1) / n_dev);
-    std::vector<focr_pipe_t *> pipes(n_dev, nullptr);
+    // one executor per device behind one handle (focr_fleet_*, include/focr_ncc.h): contexts and banks are set up in
+    // parallel, batch b goes to device b % n_dev, fleet tickets are 1, 2, 3 ... in submission order
+    focr_fleet_t *fleet = nullptr;
     {
-        std::vector<std::thread> th;  // one thread per device: context creation and bank upload in parallel
-        std::vector<std::string> errs(n_dev);
-        for (size_t d = 0; d < n_dev; d++)
-            th.emplace_back([&, d]() {
-                if (focr_pipe_create((int)d, (unsigned)n_lanes, &pipes[d]) != FOCR_OK) errs[d] = std::string("no usable GPU: ") + focr_last_error_global();
-                else if (focr_pipe_bank_upload(pipes[d], bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
-                    errs[d] = std::string("focr_bank_upload: ") + focr_last_error_global();
-                else
-                    focr_pipe_set_fetch(pipes[d], 1);  // every lane copies its batch's counts and lines to page-locked memory itself
-            });
-        for (auto &t : th) t.join();
-        for (const std::string &e : errs)
-            if (!e.empty()) fatal(e);
+        std::vector<int> devs(n_dev);
+        for (size_t d = 0; d < n_dev; d++) devs[d] = (int)d;
+        if (focr_fleet_create(devs.data(), (unsigned)n_dev, (unsigned)n_lanes, &fleet) != FOCR_OK) fatal(std::string("no usable GPU: ") + focr_last_error_global());
+        if (focr_fleet_bank_upload(fleet, bank.templates, bank.n_templates, bank.needles, bank.needles_len) != FOCR_OK)
+            fatal(std::string("focr_bank_upload: ") + focr_last_error_global());
+        focr_fleet_set_fetch(fleet, 1);  // every lane copies its batch's counts and lines to page-locked memory itself
     }
     {  // the remaining slabs, and page-lock all of them (a slab that cannot be locked still works, through a staged copy)
         const size_t want = std::min(n_batches, n_dev * n_lanes + 4);
@@ -459,10 +454,9 @@ int main(int argc, char **argv) {
     // results of batch b: read from its lane's context, formatted in page order, lane and slab released
     auto retire = [&](size_t b) {
         const Batch &B = batches[b];
-        focr_pipe_t *pipe = pipes[b % n_dev];
         focr_host_results_t R{};
         auto t0 = now();
-        if (focr_pipe_host_results(pipe, tickets[b], &R) != FOCR_OK) fatal(std::string("scan: ") + focr_last_error_global());
+        if (focr_fleet_host_results(fleet, tickets[b], &R) != FOCR_OK) fatal(std::string("scan: ") + focr_last_error_global());
         const uint32_t *counts = R.counts;
         for (size_t q = 0; q < B.n * T; q++)
             if (!args.rust && counts[q] == FOCR_MAX_MATCHES) fprintf(stderr, "WARN got >= %d matches\n", FOCR_MAX_MATCHES);  // src/ncc.rs:395-397
@@ -521,7 +515,7 @@ int main(int argc, char **argv) {
                 }
             }
         }
-        if (focr_pipe_release(pipe, tickets[b]) != FOCR_OK) fatal("focr_pipe_release failed");  // the lane's result buffers are free again
+        if (focr_fleet_release(fleet, tickets[b]) != FOCR_OK) fatal("focr_fleet_release failed");  // the lane's result buffers are free again
         if (out.size() > (1u << 20) || b + 1 == n_batches) {
             fwrite(out.data(), 1, out.size(), stdout);
             out.clear();
@@ -542,9 +536,9 @@ int main(int argc, char **argv) {
         if (!pages[0].err.empty()) fatal("cannot open image: " + pages[0].err);
         uint64_t ticket = 0;
         focr_ctx_t *ctx = nullptr;
-        if (focr_pipe_submit(pipes[0], slabs[0], 0, 1, batches[0].w, batches[0].h, 1, args.threshold, cap, mode, 0, args.anchor_threshold, args.overlap, nullptr,
-                             0, &ticket) != FOCR_OK ||
-            focr_pipe_wait(pipes[0], ticket, &ctx) != FOCR_OK)
+        if (focr_fleet_submit(fleet, slabs[0], 0, 1, batches[0].w, batches[0].h, 1, args.threshold, cap, mode, 0, args.anchor_threshold, args.overlap, &ticket) !=
+                FOCR_OK ||
+            focr_fleet_wait(fleet, ticket, &ctx) != FOCR_OK)
             fatal(std::string("scan: ") + (ctx ? focr_last_error(ctx) : focr_last_error_global()));
         std::vector<uint32_t> counts(T);
         CK(ctx, focr_get_counts(ctx, counts.data()));
@@ -564,7 +558,7 @@ int main(int argc, char **argv) {
             }
         }
         fwrite(out.data(), 1, out.size(), stdout);
-        focr_pipe_release(pipes[0], ticket);
+        focr_fleet_release(fleet, ticket);
         stop_pool();
         fflush(stdout);
         fflush(stderr);
@@ -589,9 +583,9 @@ int main(int argc, char **argv) {
             std::lock_guard<std::mutex> lk(mu);
             slab = slabs[b % n_slabs];
         }
-        if (focr_pipe_submit(pipes[b % n_dev], slab, 0, batches[b].n, batches[b].w, batches[b].h, 1, args.threshold, cap, mode, 1, args.anchor_threshold,
-                             args.overlap, nullptr, 0, &tickets[b]) != FOCR_OK)
-            fatal(std::string("focr_pipe_submit: ") + focr_last_error_global());
+        if (focr_fleet_submit(fleet, slab, 0, batches[b].n, batches[b].w, batches[b].h, 1, args.threshold, cap, mode, 1, args.anchor_threshold, args.overlap,
+                              &tickets[b]) != FOCR_OK)
+            fatal(std::string("focr_fleet_submit: ") + focr_last_error_global());
     }
     while (next_retire < n_batches) retire(next_retire++);
     stop_pool();
@@ -609,7 +603,7 @@ int main(int argc, char **argv) {
     }
     clk.lap("pages");
     fflush(stdout);
-    for (focr_pipe_t *p : pipes) focr_pipe_destroy(p);
+    focr_fleet_destroy(fleet);
     focr_bank_free(&bank);
     clk.lap("teardown");
     if (timing)

@@ -355,3 +355,81 @@ def text_of(lines, advance_px=None):
         host.focr_line_text(_ptr(line), len(line), float(advance_px or 0.0), int(advance_px is not None), buf, len(buf))
         out.append(buf.value.decode("utf-8"))
     return "\n".join(out)
+
+
+class Fleet:
+    """Every GPU of the node (focr_fleet_*, include/focr_ncc.h): one Pipeline-like executor per device, batch k -> device
+    k % n_devices; retire the tickets in submission order.  devices=None: all visible devices (the same device may be
+    listed more than once: several executors share it — what the one-GPU tests do)."""
+
+    def __init__(self, devices=None, lanes=3):
+        self._lib = N.hip()
+        h = C.c_void_p()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._lib.focr_fleet_create(arr, len(devices), int(lanes), C.byref(h))
+        else:
+            rc = self._lib.focr_fleet_create(None, 0, int(lanes), C.byref(h))
+        if rc != 0:
+            raise FocrError(self._lib.focr_last_error_global().decode())
+        self._h = h
+        self.n_devices = int(self._lib.focr_fleet_devices(h))
+        self.lanes = int(self._lib.focr_fleet_lanes(h))
+        self._views = {}  # context handle -> Scanner view
+        self._keep = {}
+        self.bank = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for sc in self._views.values():
+                sc.close()
+            self._lib.focr_fleet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_bank(self, bank):
+        rc = self._lib.focr_fleet_bank_upload(self._h, _ptr(bank.templates), len(bank.templates), _ptr(bank.needles), bank.needles.size)
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        self.bank = bank
+
+    def device_of(self, ticket):
+        return int(self._lib.focr_fleet_device_of(self._h, int(ticket)))
+
+    def submit(self, luma, threshold=0.8, cap=MAX_MATCHES, mode=SCAN_MFMA, process_hits=True, anchor_threshold=0.95, overlap=5, invert=True):
+        luma = np.ascontiguousarray(luma, np.uint8)
+        if luma.ndim == 2:
+            luma = luma[None]
+        n, r_h, r_w = luma.shape
+        t = C.c_uint64()
+        rc = self._lib.focr_fleet_submit(self._h, _ptr(luma), 0, n, r_w, r_h, int(bool(invert)), float(threshold), int(cap), int(mode),
+                                         int(bool(process_hits)), float(anchor_threshold), int(overlap), C.byref(t))
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        self._keep[t.value] = luma
+        return t.value
+
+    def wait(self, ticket):
+        """Blocks until the batch is done; returns a Scanner view of the context holding its results."""
+        h = C.c_void_p()
+        rc = self._lib.focr_fleet_wait(self._h, int(ticket), C.byref(h))
+        luma = self._keep.pop(ticket, None)
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        sc = self._views.get(h.value)
+        if sc is None:
+            sc = self._views[h.value] = Scanner(self.device_of(ticket), _borrowed=h.value)
+        sc.bank = self.bank
+        if luma is not None:
+            sc.n_pages, sc.r_h, sc.r_w = luma.shape
+        return sc
+
+    def release(self, ticket):
+        rc = self._lib.focr_fleet_release(self._h, int(ticket))
+        if rc != 0:
+            raise FocrError(f"[{rc}] focr_fleet_release: ticket is not outstanding")

@@ -294,6 +294,33 @@ int focr_pipe_wait(focr_pipe_t *pipe, uint64_t ticket, focr_ctx_t **ctx);
 /* The lane may take its next batch; the results of `ticket` are gone. */
 int focr_pipe_release(focr_pipe_t *pipe, uint64_t ticket);
 
+/* ---- every GPU of the node ------------------------------------------------
+ * The same executor over several devices (the page parallelism of src/ncc.rs:839-847 uses every core the host has; this
+ * uses every GPU): one focr_pipe per device, created and given the bank in parallel; batch k (in submission order) goes to
+ * device k % n_devices and, there, to the next lane.  Tickets are the fleet's own, 1, 2, 3 ... in submission order; retire
+ * them in that order and the output order is the submission order whatever the device count.  No collective: results
+ * converge on the host that consumes them (a device-resident consumer uses focr_rccl.h).  `devices` == NULL or
+ * n_devices == 0: all visible devices.  focr_fleet_submit blocks while the lane the batch maps to still holds an
+ * unreleased batch (at most n_devices * lanes_per_device batches are in flight); with pages_on_device != 0 the pointer
+ * must belong to focr_fleet_device_of(ticket it will get) — host pages are the normal case.  The `ncc` binary is this
+ * loop. */
+typedef struct focr_fleet focr_fleet_t;
+int focr_fleet_create(const int *devices, unsigned n_devices, unsigned lanes_per_device, focr_fleet_t **out);
+void focr_fleet_destroy(focr_fleet_t *fleet);
+unsigned focr_fleet_devices(const focr_fleet_t *fleet);
+unsigned focr_fleet_lanes(const focr_fleet_t *fleet);
+focr_pipe_t *focr_fleet_pipe(focr_fleet_t *fleet, unsigned index);  /* the executor of the index-th device */
+int focr_fleet_device_of(const focr_fleet_t *fleet, uint64_t ticket);  /* HIP device index ticket maps / will map to */
+int focr_fleet_bank_upload(focr_fleet_t *fleet, const focr_template_t *templates, size_t n_templates,
+                           const uint8_t *needles, size_t needles_len);
+int focr_fleet_set_fetch(focr_fleet_t *fleet, int on);
+int focr_fleet_submit(focr_fleet_t *fleet, const void *pages, int pages_on_device, size_t n_pages, size_t r_w, size_t r_h,
+                      int invert, float threshold, uint32_t cap, int mode, int process_hits, float anchor_threshold,
+                      int32_t overlap, uint64_t *ticket);
+int focr_fleet_wait(focr_fleet_t *fleet, uint64_t ticket, focr_ctx_t **ctx);
+int focr_fleet_host_results(focr_fleet_t *fleet, uint64_t ticket, focr_host_results_t *out);
+int focr_fleet_release(focr_fleet_t *fleet, uint64_t ticket);
+
 /* Per-launch record of the scan kernels of the last focr_scan (one entry per
  * (size class, bank chunk) launch), timed with HIP events on the stream the
  * kernel ran on.  alg_macs: true template area x searched windows x templates

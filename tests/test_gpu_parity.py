@@ -846,3 +846,48 @@ def test_pipeline_soak_mfma_equals_direct():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_pipeline.py"), "--batches", "60", "--pages", "12"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_fleet_orders_batches_over_devices(bank_x2):
+    """focr_fleet_* (the multi-device executor of the C ABI): batch k goes to device k % n_devices; retired in submission order
+    the results are those of a single context, whatever the device count.  The one GPU of the test box is listed twice
+    (two executors, four contexts on it), which exercises the ticket arithmetic of a two-device fleet."""
+    from font_ocr_amd.searcher import Fleet
+
+    bank = bank_x2.subset(list(range(33, 70)) + list(range(95 + 33, 95 + 70)))
+    batches = [synth_pages(bank_x2, 1 + (k % 3), 300, 130, first=9000 + 10 * k) for k in range(9)]
+    want = []
+    with Scanner(0) as sc:
+        sc.set_bank(bank)
+        for pg in batches:
+            sc.set_pages(pg)
+            sc.scan(0.8, 1024, SCAN_MFMA)
+            sc.process_hits(0.95, 5)
+            want.append((sc.counts().copy(), sc.matches()[1].tobytes(), sc.lines_flat().tobytes()))
+    assert sum(len(w[2]) for w in want) > 1000
+    for devices in ([0], [0, 0]):
+        fl = Fleet(devices, lanes=2)
+        try:
+            assert fl.n_devices == len(devices) and fl.lanes == 2
+            fl.set_bank(bank)
+            inflight, got = [], []
+
+            def retire():
+                t = inflight.pop(0)
+                assert fl.device_of(t) == 0
+                v = fl.wait(t)
+                got.append((v.counts().copy(), v.matches()[1].tobytes(), v.lines_flat().tobytes()))
+                fl.release(t)
+
+            for k, pg in enumerate(batches):
+                if len(inflight) == fl.n_devices * fl.lanes:
+                    retire()
+                t = fl.submit(pg, 0.8, 1024, SCAN_MFMA, True, 0.95, 5)
+                assert t == k + 1
+                inflight.append(t)
+            while inflight:
+                retire()
+            for k in range(len(batches)):
+                assert np.array_equal(got[k][0], want[k][0]) and got[k][1] == want[k][1] and got[k][2] == want[k][2], (devices, k)
+        finally:
+            fl.close()
