@@ -1,12 +1,16 @@
-// scan_mfma2.hip — barrier-free i8 MFMA prefilter (default variant).
+// scan_mfma2.hip — the barrier-free i8 MFMA prefilter kernels.
 //
-// The maths is in scan_mfma.hip's header, the K layouts in mfma_common.h.  Every wave is an independent worker: it takes MT
-// consecutive 16-window M-tiles of the (page, row, column) enumeration, reads its A fragments
-// straight from the page in HBM/L2 (two aligned loads + v_alignbyte per 16-byte k-group; the page
-// is read ~16x per class, all but the first time from L2), and streams the whole quantised bank
-// chunk past them from LDS.  The bank is staged once per block, so the kernel has exactly one
-// barrier; there is no per-tile fill/drain, and with 128 windows per wave a B fragment (1 KiB
-// ds_read_b128) feeds 8 MFMAs.  One 512-thread block per CU, 2 waves per SIMD, <= 256 VGPRs.
+// The maths is in scan_mfma.hip's header, the K layouts and the item queues in mfma_common.h.  Every wave is an independent
+// worker: it takes items of MT consecutive 16-window M-tiles from its XCD's queue, reads its window fragments straight from
+// the page in HBM/L2 (byte-unaligned global loads that land in the MFMA operand registers; the page is read ~16x per class,
+// all but the first time from L2), and streams the whole quantised bank chunk past them from LDS.  The bank is staged once
+// per workgroup, so a kernel has exactly one barrier; there is no per-tile fill/drain.  One workgroup per CU.
+//
+//   scan_mfma2s_kernel  the default (<= 4 K-steps, <= 4 size classes per pass): A = templates, B = windows, the C-in of a
+//                       lane is the threshold of its own window, formed in registers from f16 window norms; 16 waves x 4
+//                       M-tiles per CU, 128 VGPRs.
+//   scan_mfma2_kernel   round 1's form (A = windows, int32 negL rows re-loaded per size class), kept for 5..8 K-steps and
+//                       as a cross-check (FOCR_PREFILTER_LEGACY); 8 waves x 4..8 M-tiles for the long layouts.
 #include <algorithm>
 
 #include "mfma_common.h"
