@@ -79,9 +79,11 @@ def main():
     ap.add_argument("--c4-pages", type=int, default=8192, help="total pages of --config c4 (BASELINE configs[3]: 8192)")
     ap.add_argument("--mode", choices=["mfma", "direct"], default="mfma")
     ap.add_argument("--threshold", type=float, default=0.8)
-    ap.add_argument("--prefilter", choices=["auto", "one", "two", "legacy"], default="auto",
-                    help="MFMA prefilter (focr_ctx_set_prefilter): auto = one stage; two = low-rank bound first (scan_mfma3.hip); "
+    ap.add_argument("--prefilter", choices=["auto", "one", "legacy"], default="auto",
+                    help="MFMA prefilter kernel (focr_ctx_set_prefilter): auto = one = threshold planes + scan_mfma2s_kernel; "
                          "legacy = round 1's kernel and int32 threshold tables")
+    ap.add_argument("--no-column-drop", action="store_true",
+                    help="multiply every template column in the MFMA (focr_ctx_set_column_drop(0)): round 2's 3-K-step form of the 9-wide classes, for A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pages", type=int, default=0, help="0 = 4 pages per host thread")
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
@@ -144,6 +146,9 @@ def main():
     from font_ocr_amd.searcher import Pipeline
 
     pipe = Pipeline(local_rank, n_ctx)
+    if args.no_column_drop:
+        for c_ in pipe.scanners:
+            c_.set_column_drop(False)
     pipe.set_bank(bank)
     scs, pages = [], None
     shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM
@@ -160,7 +165,7 @@ def main():
         for j in range(n_ctx):
             c_ = pipe.scanners[j]
             c_.set_scan_cus(scan_cus)
-            c_.set_prefilter({"auto": 0, "one": 1, "two": 2, "legacy": 3}[args.prefilter])
+            c_.set_prefilter({"auto": 0, "one": 1, "legacy": 3}[args.prefilter])
             scs.append(c_)
     for j in range(n_ctx if shard is None else 0):  # every rank (and every context of it) scans its own shard of the page set
         if args.noise:
@@ -171,7 +176,7 @@ def main():
             pages = pg
         c_ = pipe.scanners[j]
         c_.set_scan_cus(scan_cus)
-        c_.set_prefilter({"auto": 0, "one": 1, "two": 2, "legacy": 3}[args.prefilter])
+        c_.set_prefilter({"auto": 0, "one": 1, "legacy": 3}[args.prefilter])
         # inputs resident in HBM before the timed region: pages go up as a torch tensor, then device->device ingest
         d_pages = torch.from_numpy(pg).to(dev)
         c_.alloc_pages(P, R_W, R_H)
@@ -425,6 +430,7 @@ def main():
             "templates": len(bank),
             "scan_mode": args.mode,
             "prefilter": args.prefilter,
+            "column_drop": not args.no_column_drop,
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
         },
     }

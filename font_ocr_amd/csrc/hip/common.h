@@ -24,25 +24,13 @@ struct SizeClass {
     uint32_t n_templates;  // templates in this class
     uint32_t first;        // index of the class's first entry in the class-ordered arrays
     // MFMA prefilter layout
+    uint32_t keep_w;          // columns the MFMA multiplies: n_w, or n_w - 1 for a class whose last column is bounded instead
+                              // (n_w = 9, 13: one K layout narrower; mfma_common.h, "threshold planes")
     uint32_t layout;          // K layout of the MFMA prefilter (LAYOUT_W8 / W12 / W16, mfma_common.h)
     uint32_t k_groups;        // 16-byte k-groups per window (multiple of 4)
     uint32_t n_tiles16;       // ceil(n_templates / 16)
     uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
     uint32_t tg_offset;       // entry offset of the class's template ids in d_tglobal (16 per N-tile, ~0 = padding/dead)
-};
-
-// Two-stage prefilter data of one super-class (lowrank.hip builds it, scan_mfma3.hip uses it).
-constexpr uint32_t LR_K = 32;            // K of the stage-2 bf16 MFMA: r principal directions + R + N_F + one slot per class
-constexpr uint32_t LR_BASIS_TILES = 2;   // stage 1 computes 32 rows (the last LR_K - r of them are zero)
-constexpr uint32_t LR_MAX_CLASSES = 4;
-struct LowRank {
-    bool available = false;
-    uint32_t r = 0, n_cls = 0, frame_w = 0, frame_h = 0, n_live = 0;
-    int frame_class = -1;      // position (inside the super-class) of the class whose box is the frame, -1 if none
-    size_t basis_offset = 0;   // bytes into d_lr_basis
-    size_t g_offset = 0;       // bytes into d_lr_g (1 KiB per N-tile of the super-class)
-    float inv_lambda = 0.f;    // sum_j y_j^2 * inv_lambda <= |P (a - mean)|^2
-    double mean_rho = 0, max_rho = 0;
 };
 
 // Classes whose A fragments are identical (same K layout, same number of K-steps) are scanned in one kernel
@@ -56,7 +44,6 @@ struct SuperClass {
     // per scan: window enumeration of the pass (smallest searchable template) and its live-tile list
     uint32_t min_w, min_h, mtx, n_rows;
     size_t live_offset;
-    LowRank lr;
 };
 
 // Per-template constants, computed once on the host in IEEE double exactly as
@@ -108,10 +95,7 @@ struct focr_ctx {
     uint32_t *d_direct_bank = nullptr;          // class-ordered, [maxh][ndw] dwords each
     std::vector<size_t> direct_bank_off;        // dword offset per class
     int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
-    int8_t *d_lr_basis = nullptr;               // two-stage prefilter: int8 basis rows (per-lane MFMA layout), all super-classes
-    std::vector<uint8_t> h_dense;               // class-ordered dense needles (host copy for the lazily built two-stage data)
-    bool lr_built = false;
-    uint16_t *d_lr_g = nullptr;                 // two-stage prefilter: bf16 stage-2 operand, 1 KiB per N-tile
+    bool column_drop = true;                    // bound the last column of 9- / 13-wide classes instead of multiplying it (takes effect at the next bank upload)
     // ---- result sizes (ctx.hip: finish_results) ----
     // Every phase after the scan kernel takes its element count from device memory; the host only supplies upper bounds for
     // grids and buffers.  Exact mode reads the counts between the phases (as round 1 did); estimated mode (same bank,
@@ -134,12 +118,12 @@ struct focr_ctx {
     int scan_mode = 0;
     int32_t post_overlap = 0;
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
-    int prefilter = 0;                          // FOCR_PREFILTER_*: auto / single stage / two stages (focr_ctx_set_prefilter)
-    uint16_t *d_norms = nullptr;                // window norms as f16, planar: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
-    size_t norms_bytes = 0;
+    int prefilter = 0;                          // FOCR_PREFILTER_*: auto / plane kernel / legacy kernel (focr_ctx_set_prefilter)
+    uint16_t *d_planes = nullptr;               // threshold planes, f16: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
+    size_t planes_bytes = 0;
     uint32_t *d_tglobal = nullptr;              // class-ordered -> global template index, 0xffffffff = never emits
     uint32_t *d_order_of = nullptr;             // global template index -> class-ordered index
-    std::vector<double> mfma_c_scale, mfma_e_max;  // per class: quantisation scale, max rounding-error norm
+    std::vector<double> mfma_c_scale, mfma_e_max, mfma_rho_max;  // per class: quantisation scale, max rounding-error norm, max norm of a unit template's dropped column
     uint8_t *d_needles = nullptr;               // dense needles (class-ordered, for verify)
     std::vector<uint32_t> h_needle_off;         // class-ordered byte offsets into d_needles
     uint32_t *d_needle_off = nullptr;
@@ -241,7 +225,7 @@ int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
 void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
                        std::vector<uint32_t> &direct, std::vector<uint8_t> &dense);
 void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layouts, bank offsets (host only)
-void build_lowrank(focr_ctx *c, SuperClass &su, const uint8_t *dense, std::vector<int8_t> &basis_bytes, std::vector<uint16_t> &g_bytes);
+int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of);  // host only
 
 // ---- device helpers: the reference's f64 epilogue, operation for operation ----
 // Compiled with -ffp-contract=off: the only fused operation is the explicit fma.

@@ -69,12 +69,11 @@ static void free_bank(focr_ctx *c) {
     free_dev(c->d_tconst);
     free_dev(c->d_direct_bank);
     free_dev(c->d_qbank);
-    free_dev(c->d_lr_basis);
-    free_dev(c->d_lr_g);
     free_dev(c->d_tglobal);
     free_dev(c->d_order_of);
     c->mfma_c_scale.clear();
     c->mfma_e_max.clear();
+    c->mfma_rho_max.clear();
     free_dev(c->d_needles);
     free_dev(c->d_needle_off);
     free_dev(c->d_needles16);
@@ -106,8 +105,8 @@ static void free_results(focr_ctx *c) {
                     &c->acc_hkeys, &c->acc_hsims})
         b->release();
     free_dev(c->d_L);
-    free_dev(c->d_norms);
-    c->norms_bytes = 0;
+    free_dev(c->d_planes);
+    c->planes_bytes = 0;
     free_dev(c->d_sort_tmp);
     free_dev(c->d_seg_count);
     free_dev(c->d_seg_start);
@@ -267,8 +266,15 @@ int focr_ctx_set_scan_cus(focr_ctx_t *c, unsigned max_cus) {
 }
 
 int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
-    if (!c || mode < FOCR_PREFILTER_AUTO || mode > FOCR_PREFILTER_LEGACY) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
+    if (!c || (mode != FOCR_PREFILTER_AUTO && mode != FOCR_PREFILTER_ONE_STAGE && mode != FOCR_PREFILTER_LEGACY))
+        return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
     c->prefilter = mode;
+    return FOCR_OK;
+}
+
+int focr_ctx_set_column_drop(focr_ctx_t *c, int on) {
+    if (!c) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_column_drop: null context");
+    c->column_drop = on != 0;
     return FOCR_OK;
 }
 

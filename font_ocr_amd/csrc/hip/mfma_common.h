@@ -1,4 +1,5 @@
-// mfma_common.h — declarations shared by the MFMA prefilter kernels (scan_mfma.hip, scan_mfma2.hip).
+// mfma_common.h — declarations shared by the MFMA prefilter kernels (scan_mfma.hip, scan_mfma2.hip): threshold planes,
+// item queues, K layouts.
 #pragma once
 #include "common.h"
 
@@ -19,21 +20,130 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
     if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
 }
 
+// ---- threshold planes ------------------------------------------------------------------------
+// The statistics kernel turns every window of a size class into ONE number, the prefilter threshold L of that window, and
+// stores it as f16 in units of a per-class power of two S ("threshold plane", 2 B per window and class):
+//
+//     L(w) = kappa * norm_p(w)  -  c * rho_max * dnorm(w)            candidate  <=>  G(w, t) > L(w)
+//
+// kappa = c*thr - e_max - margins (scan_mfma.hip header).  The second term exists for classes whose LAST COLUMN the MFMA
+// does not multiply ("column drop": a 9-wide template costs 3 K-steps of 64 bytes for 135 taps; its first 8 columns fit 2):
+// with m = mean of the window over the kept columns, beta = the unit mean-centred template, sigma = sum of beta over the
+// dropped column, and beta'_k = beta_k + sigma / n_keep on the kept columns (so that sum beta' = 0),
+//     sum_all a_k beta_k = sum_keep a_k beta'_k + sum_drop (a_j - m) beta_j          (exact)
+// the MFMA evaluates the first sum with the int8 rounding of c*beta' (error <= e_max * norm_keep <= e_max * norm_p: the kept
+// box's norm about its own mean never exceeds the full box's), and Cauchy-Schwarz bounds the second by
+// dnorm(w) * rho_t,  dnorm = |a_drop - m|_2,  rho_t = |beta_drop|_2 <= rho_max.  Hence sim > thr  =>  G > L: no false
+// negatives, for either sign of kappa.  Everything up to the square roots is exact integer arithmetic:
+//     V = n*s2 - s^2 = n * norm_p^2                                  (full box; V > 0 <=> the reference's rnorm is finite)
+//     W = n_k^2*q2 - 2*n_k*s_k*q1 + D*s_k^2 = n_k^2 * dnorm^2        (q1, q2: sums over the dropped column, D its taps)
+// then L = kq*sqrt(V) - crk*sqrt(W) in f32 with kq rounded towards -inf and crk up (host: plane_params) — f32 errors stay
+// below 1 for |L| < 4e6 and are absorbed by the "- 2" of prefilter_cin — and the stored value is L / S rounded TOWARDS -INF
+// to f16 (a lower threshold only admits more candidates), +inf where the reference never emits (x = 0, y = 0, window outside
+// the page, zero variance).  Round 2 stored the window norm (rounded towards zero) and multiplied by kappa in the scan
+// kernel, which raised the threshold for kappa < 0; a directed rounding of L itself has no sign cases.
+struct PlaneParams {
+    float kq;     // kappa / sqrt(n), towards -inf
+    float crk;    // c * rho_max * (1 + 1e-4) / n_keep, upwards (0: nothing dropped)
+    float S;      // power of two: |L| / S < 32768 for every window
+    float inv_S;  // 1 / S (exact)
+};
+
+// f32 -> f16 bits, rounded towards -inf (|x| < 65504)
+__host__ __device__ inline uint16_t f16_down(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x, 0.f);  // towards zero
+    uint32_t h = __builtin_bit_cast(uint32_t, h2) & 0xffffu;
+    const float back = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+    if (back > x) h += 1;  // only negative x: one step away from zero (-0 -> the smallest negative subnormal)
+    return (uint16_t)h;
+#else
+    const uint32_t u = __builtin_bit_cast(uint32_t, x), sign = u >> 31, a = u & 0x7fffffffu;
+    uint32_t h;
+    bool inexact;
+    if (a >= 0x47800000u) {  // out of range: callers never get here
+        h = 0x7bff;
+        inexact = true;
+    } else if (a >= 0x38800000u) {  // normal f16
+        h = (a - 0x38000000u) >> 13;
+        inexact = (a & 0x1fffu) != 0;
+    } else if (a >= 0x33000000u) {  // subnormal f16: value = h * 2^-24
+        const uint32_t e = a >> 23, m = (a & 0x7fffffu) | 0x800000u, shift = 126 - e;
+        h = m >> shift;
+        inexact = (m & ((1u << shift) - 1)) != 0;
+    } else {
+        h = 0;
+        inexact = a != 0;
+    }
+    if (sign && inexact) h += 1;
+    return (uint16_t)(h | (sign << 15));
+#endif
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+constexpr uint16_t PLANE_NEVER = 0x7c00;  // +inf: the reference never emits at this window
+
+// f32 square root: the raw 1-ulp instruction on the device, the correctly rounded one in the host model
+__host__ __device__ inline float sqrt_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
+// L of one window in f32 from its exact integer statistics (see above).  V, W as floats (conversion error 2^-24 relative).
+__host__ __device__ inline float threshold_f32(const PlaneParams &p, float Vf, float Wf) {
+    return __builtin_fmaf(-p.crk, sqrt_fast(Wf), p.kq * sqrt_fast(Vf));
+}
+// W = n_k^2 * dnorm^2, exact (fits 64 bits: n_k <= 512, sums of <= 32 taps)
+__host__ __device__ inline uint64_t dropped_column_W(uint32_t n_k, uint32_t D, uint32_t s_k, uint32_t q1, uint32_t q2) {
+    return (uint64_t)n_k * n_k * q2 + (uint64_t)D * s_k * s_k - 2ull * n_k * (uint64_t)s_k * q1;
+}
+// legacy int32 table entry (scan_mfma2_kernel): -(floor(L) - 2)
+__host__ __device__ inline int32_t threshold_negL(float Lf) {
+    float f = __builtin_floorf(Lf) - 2.0f;
+    f = __builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f);
+    return -(int32_t)f;
+}
+// C-in of one window from its plane value v (as f32; +inf = never): -(floor(S * v) - 2).  S * v is exact (S a power of two).
+__host__ __device__ inline int prefilter_cin(float S, float v) {
+    float f = __builtin_floorf(S * v) - 2.0f;
+    f = __builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f);  // +inf -> an unreachable threshold (|G| < 2^24)
+    return -(int)f;
+}
+
 // How the waves of a persistent scan kernel get their work.  Items (MT consecutive live M-tiles) are split into one
 // contiguous range per XCD: workgroups b and b + 8 share an XCD and its L2, and neighbouring M-tiles share page rows.  Inside
-// a range the waves TAKE items from a queue (one agent-scope atomic per item, requested one item ahead so that its latency
-// is never waited for) instead of owning a fixed stride: a workgroup needs an empty CU (all of its LDS, all 512 VGPRs of
-// each SIMD), so with other contexts' kernels on the GPU the workgroups of one launch start up to a few 100 us apart, and
-// the time per item varies with the candidates it finds; under a fixed split the launch ends when its unluckiest wave does
-// (BASELINE configs[1], alone on the GPU: 2.20 -> 1.83 ms).  A wave whose range is exhausted goes on with the next XCD's; it
-// stops once it has seen every range exhausted, which every wave reaches after at most n_xc extra requests.
+// a range the waves TAKE items from a queue instead of owning a fixed stride: a workgroup needs an empty CU (all of its LDS,
+// all 512 VGPRs of each SIMD), so with other contexts' kernels on the GPU the workgroups of one launch start up to a few
+// 100 us apart, and the time per item varies with the candidates it finds; under a fixed split the launch ends when its
+// unluckiest wave does (BASELINE configs[1], alone on the GPU: 2.20 -> 1.83 ms).
+// A ticket (one agent-scope atomic on the range's counter, requested while the wave still works on the last item it holds,
+// so that its latency is never waited for) grants ITEMS_PER_TICKET consecutive items: one counter word serves about 88
+// returning atomics per microsecond (MI355X_MICROARCH.md, "dequeue"), and BASELINE configs[1] has 87 000 items per XCD —
+// with one item per ticket the queue itself set a floor of ~1 ms under the launch (round 2: 1.26 ms for a 6-N-tile bank whose
+// MFMAs take 0.3 ms).  A wave whose range is exhausted goes on with the next XCD's; it stops once it has seen every range
+// exhausted, which every wave reaches after at most n_xc extra requests.
 // The queue (QUEUE_XCDS counters, QUEUE_STRIDE dwords apart) is zeroed by the memset that opens every scan (launch_scan_mfma).
+#ifndef FOCR_ITEMS_PER_TICKET
+#define FOCR_ITEMS_PER_TICKET 4
+#endif
+constexpr uint32_t ITEMS_PER_TICKET = FOCR_ITEMS_PER_TICKET;
 struct ItemTaker {
     uint32_t *queue;
     uint32_t n_items, n_xc, per_xc, cur_q, hops, ticket_v;
+    uint32_t b_cur, b_end;  // items of the current ticket not handed out yet (wave-uniform)
+    bool want;              // the current ticket's last item has been handed out: request() asks for the next ticket
     int lane;
-    __device__ __forceinline__ void request() {
+    __device__ __forceinline__ void ask() {
         if (lane == 0) ticket_v = __hip_atomic_fetch_add(queue + cur_q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // call once per item, after the item's loads have been issued: asks for the next ticket when this was the ticket's last item
+    __device__ __forceinline__ void request() {
+        if (want) {
+            want = false;
+            ask();
+        }
     }
     __device__ __forceinline__ void init(uint32_t *q, uint32_t items, int lane_) {
         queue = q;
@@ -44,21 +154,31 @@ struct ItemTaker {
         cur_q = blockIdx.x % n_xc;
         hops = 0;
         ticket_v = 0;
-        request();
+        b_cur = b_end = 0;
+        want = false;
+        ask();
     }
-    // the wave's next item (wave-uniform), or false when there is none left.  Call request() once per item, after the item's
-    // loads have been issued, for the ticket this reads the next time round.
+    // the wave's next item (wave-uniform), or false when there is none left
     __device__ __forceinline__ bool next(uint32_t &item) {
+        if (b_cur < b_end) {
+            item = b_cur++;
+            want = b_cur == b_end;
+            return true;
+        }
         for (;;) {
             const uint32_t ticket = __builtin_amdgcn_readfirstlane(ticket_v);
             const uint32_t qb = cur_q * per_xc, qe = min(n_items, qb + per_xc);
-            if (qb < qe && ticket < qe - qb) {
-                item = qb + ticket;
+            // ticket * ITEMS_PER_TICKET cannot wrap: tickets <= items / ITEMS_PER_TICKET + waves of the launch
+            if (qb < qe && ticket < (qe - qb + ITEMS_PER_TICKET - 1) / ITEMS_PER_TICKET) {
+                b_cur = qb + ticket * ITEMS_PER_TICKET;
+                b_end = min(qe, b_cur + ITEMS_PER_TICKET);
+                item = b_cur++;
+                want = b_cur == b_end;
                 return true;
             }
             if (++hops >= n_xc) return false;
             cur_q = cur_q + 1 == n_xc ? 0 : cur_q + 1;
-            request();
+            ask();
         }
     }
 };
@@ -71,8 +191,8 @@ struct ItemTaker {
 //   LAYOUT_W12 (n_w 9..12) : rows are 12 bytes = 3 dwords; a quad of rows (4m..4m+3) fills exactly three groups, one per
 //     dword COLUMN c = 0, 1, 2: group (m, c) = dword c (columns 4c..4c+3) of rows 4m, 4m+1, 4m+2, 4m+3.
 //     (K-step, lane group) of group (m, c): ks = 3*(m/4) + c, g = m%4 — a K-step is a 4-column strip of 16 rows, so the
-//     last K-step of a 16-row block holds nothing but zeros for templates of n_w <= 8 and the kernels skip its MFMAs for
-//     such a size class (Mfma3Args::seg_full).  A lane loads its 4 rows once (12 contiguous bytes each) whatever the order.
+//     last K-step of a 16-row block holds nothing but zeros for templates of kept width <= 8 and the kernels skip its MFMAs for
+//     such a size class (PlaneArgs::seg_full).  A lane loads its 4 rows once (12 contiguous bytes each) whatever the order.
 //     16 rows -> 3 K-steps (192 bytes) instead of 4.
 // Template bytes outside n_w x n_h are zero, so the extra image bytes the A side picks up do not matter.
 enum { LAYOUT_W16 = 1, LAYOUT_W8 = 2, LAYOUT_W12 = 3 };
@@ -119,47 +239,22 @@ struct MfmaLaunch {
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)
 };
 
-// ---- two-stage prefilter (scan_mfma3.hip; host data: lowrank.hip) ----
-// Window norms of one super-class, planar: norms[v][page][Lrows][Lpitch] as f16 rounded towards zero (a lower bound of the
-// norm, at most 2^-10 below it), value v = sqrt(V / n) of box v
-// (V = n*s2 - s^2, exact integer).  Values 0 .. n_cls-1 are the super-class's size classes and carry the class's emit
-// flag in the sign (> 0: the reference can emit there: x, y >= 1, window inside the page, variance > 0; <= 0: never);
-// when no class has the frame's box, one more value holds the frame norm.  |value| is always the norm.
-constexpr int LR_MAX_VALUES = 4;
-// Stage-2 K slots (LR_K = 32): slot = 16 b + 4 g + v lives in lane group g, element 4 b + v of the 8-element bf16
-// operand.  The 2 + n_cls "extras" (R, N_F, one threshold slot per class) sit at compile-time element positions so the
-// kernel places them with a select on the lane group only: extra e < 4 -> element 7 of lane group e, extra e >= 4 ->
-// element 6 of lane group e - 4.  The r principal directions fill the remaining slots in increasing slot order.
-__host__ __device__ inline uint32_t lr_extra_slot(uint32_t e) { return e < 4 ? 16 + 4 * e + 3 : 16 + 4 * (e - 4) + 2; }
-inline uint32_t lr_comp_slot(uint32_t j, uint32_t n_extras) {  // host: slot of principal direction j
-    for (uint32_t s = 0, k = 0; s < LR_K; s++) {
-        bool is_extra = false;
-        for (uint32_t e = 0; e < n_extras; e++) is_extra |= lr_extra_slot(e) == s;
-        if (is_extra) continue;
-        if (k == j) return s;
-        k++;
-    }
-    return 0xffffffffu;
-}
-
-struct Mfma3Args {
-    const uint16_t *norms;   // f16 bits: value 0 of the sub-batch's first page; values are `norm_stride` elements apart
-    size_t norm_stride;      // elements between consecutive values
-    uint32_t nv, n_cls, frame_value;  // frame_value: index of the value that holds the frame norm
-    float inv_lambda;
-    float thr_lo;            // thr_eff widened by 2^-20 away from the emitting side: theta = thr_lo * norm_c is a lower bound
-    uint32_t theta_add;      // 0xffff if thr_lo < 0 (bf16 rounding of theta towards -inf), else 0
-    float kq[MAX_SEGS];      // per segment of the launch: L = floor(kq * norm_c) - 2, the exact-taps stage's threshold
-    uint32_t seg_value[MAX_SEGS];  // per segment: the norm value of its class
-    uint32_t seg_full[MAX_SEGS];   // per segment: 0 if the class's templates are all zero in the last K-step (LAYOUT_W12, n_w <= 8)
+// Per-launch description of the threshold planes of the pass's size classes (scan_mfma2s_kernel).
+constexpr int MAX_PLANE_VALUES = 4;  // size classes per pass on the plane path (the kernel is instantiated for 1 / 2 / 4)
+struct PlaneArgs {
+    const uint16_t *planes;  // f16 bits: value 0 of the sub-batch's first page; values are `stride` elements apart
+    size_t stride;
+    uint32_t nv;
+    float S[MAX_SEGS];             // per segment of the launch: the unit of its class's plane
+    uint32_t seg_value[MAX_SEGS];  // per segment: the plane (value) of its class
+    uint32_t seg_full[MAX_SEGS];   // per segment: 0 if the class's templates are all zero in the last K-step (LAYOUT_W12, kept width <= 8)
 };
 
-// scan_mfma3.hip
-uint32_t mfma3_chunk_tiles(uint32_t ksteps);
-int dispatch_mfma_v3(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, const int8_t *basis, const uint16_t *gbank, unsigned n_cus);
+// scan_mfma.hip (host)
+PlaneParams plane_params(const focr_ctx *c, size_t k, double thr_d);
 // scan_mfma2.hip
 uint32_t mfma2_chunk_tiles(uint32_t ksteps);
-int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus);  // roles swapped, norms instead of negL
-int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);
+int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A, unsigned n_cus);  // A = templates, B = windows, threshold planes
+int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus);                       // A = windows, int32 negL tables
 
 }  // namespace focr

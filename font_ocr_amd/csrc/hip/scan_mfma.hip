@@ -16,8 +16,11 @@
 //         | c*num/norm_n - G | = | sum_k (a_k - mean_w) e_k | <= norm_p * ||e_t||_2
 //     hence sim > thr  ==>  G > (c*thr - max_t ||e_t||) * norm_p =: kappa * norm_p.  The filter
 //     has no false negatives; kappa carries an extra relative margin for the f64 roundings of
-//     the exact formula, and a stored norm below the true one only lowers the threshold.  Survivors (a few per 10^5
-//     pairs) go to a candidate list.  (FOCR_PREFILTER_TWO_STAGE puts a low-rank bound in front: scan_mfma3.hip.)
+//     the exact formula.  The stored f16 norm is a lower bound of norm_p: for kappa >= 0 that only lowers the threshold;
+//     for kappa < 0 (negative --threshold) kappa * norm_p falls as the norm grows, so the C-in is formed from the norm's
+//     upper bound instead (prefilter_cin, mfma_common.h; host model focr_debug_prefilter + tests/test_prefilter_host.py).
+//     Survivors (a few per 10^5 pairs) go to a candidate list.  (An experiment build puts a low-rank bound in front:
+//     scan_mfma3.hip.)
 //  3. exact verify (verify_kernel): the reference formula, operation for operation (common.h),
 //     on every candidate -> flags -> order.hip.
 //
@@ -46,29 +49,42 @@ int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t
 
 
 // ---------------------------------------------------------------------------------------------
-// 1. window statistics -> negL table
+// 1. window statistics -> threshold planes (or the legacy int32 tables)
 //
 // Separable sliding sums: a block stages a (64 + n_w) x (32 + n_h - 1) byte tile, computes the horizontal
 // n_w-sums H (and H2 of squares) of every tile row once (v_dot4 on masked dwords), then each thread slides a
 // vertical n_h-window down its column: S(y+1) = S(y) + H(y+n_h) - H(y).  ~40 instructions per window instead
-// of ~300 for the direct evaluation.  Everything up to the threshold is exact integer arithmetic:
-//   V = n*s2 - s*s  (= n * norm2, exact),  window is live  <=>  V > 0
-// which is exactly the reference's "norm > 0" (src/ncc.rs:309: (f64)s2 - (f64)(s*s)/(f64)n is > 0 iff V > 0,
-// = 0 iff V = 0, because V/n >= 1/n is far above the rounding error of the division).
-// negL = -(floor(kq * sqrt(V)) - 2) with kq = kappa/sqrt(n) rounded toward -inf in f32: conservative
-// (f32 sqrt/convert/multiply errors are < 1 for |L| < 4e6; the -2 absorbs them).
+// of ~300 for the direct evaluation.  Everything up to the square roots is exact integer arithmetic (V, W of
+// mfma_common.h, "threshold planes"); window is live  <=>  V > 0, which is exactly the reference's "norm > 0"
+// (src/ncc.rs:309: (f64)s2 - (f64)(s*s)/(f64)n is > 0 iff V > 0, = 0 iff V = 0, because V/n >= 1/n is far above the
+// rounding error of the division).
+//   DROP: the class's last column is bounded, not multiplied: the thread also slides the sums of that one column (bytes of
+//         the tile) down, which gives the kept box's sums and W.
+//   PAIR: the kept box is itself a size class of the pass (BASELINE configs[1]: 8x15 beside 9x15): its plane comes out of
+//         the same launch (its statistics are the kept box's), one launch instead of two.
 constexpr int STX = 64, STY = 32, SLDW = 21;
 static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h - 1) * (SLDW * 4 + STX * 4 + STX * 2); }
 
-// NORMS: instead of the int32 threshold the kernel stores the window norm sqrt(V / n) as f32 (kq = 1 / n), its sign
-// carrying the emit flag (mfma_common.h, "window norms"): the C-in is then formed inside the scan kernel from it
-// (scan_mfma2s_kernel, scan_mfma3_kernel).  mark = 0: a box that is no size class (the two-stage prefilter's frame):
-// plain norms, no live-tile marks.
-template <int NDW, bool SMALLN, bool NORMS>
+struct StatsOut {  // what a statistics launch writes for one size class
+    PlaneParams p;
+    void *out;     // OUT = 1: f16 threshold plane, OUT = 0: int32 negL table; [page][Lrows][Lpitch]
+};
+
+template <int OUT>
+__device__ __forceinline__ void stats_store(const StatsOut &o, size_t idx, bool emit, float Lf) {
+    if (OUT) {
+        Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+        reinterpret_cast<uint16_t *>(o.out)[idx] = emit ? f16_down(Lf * o.p.inv_S) : PLANE_NEVER;
+    } else {
+        reinterpret_cast<int32_t *>(o.out)[idx] = emit ? threshold_negL(Lf) : -REJECT;
+    }
+}
+
+template <int NDW, bool SMALLN, int OUT, bool DROP, bool PAIR>
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
-                                                    uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, float kq,
-                                                    int32_t *__restrict__ negL, uint32_t Lpitch, uint32_t Lrows,
-                                                    uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t mark) {
+                                                    uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, const StatsOut A,
+                                                    const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
+                                                    uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows) {
     // dynamic LDS, sized for this class's n_h (stats_lds_bytes): ~21 KB at n_h = 15 -> 7 blocks per CU; the kernel
     // lives on that occupancy (global-load latency, two barriers per tile)
     extern __shared__ uint32_t stats_lds[];
@@ -110,16 +126,22 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     if (x >= Lpitch) return;
     constexpr uint32_t PER = STY / 4;  // window rows per thread
     const uint32_t r0 = strip * PER;
-    uint32_t s = 0, s2 = 0;
+    // the class's last column as bytes of the tile (DROP): column x + n_w - 1 of the page = byte col + n_w - 1 of a tile row
+    const uint8_t *lastc = reinterpret_cast<const uint8_t *>(&tile[0][0]) + col + n_w - 1;
+    uint32_t s = 0, s2 = 0, q1 = 0, q2 = 0;
     for (uint32_t j = 0; j < n_h; j++) {
         s += H[r0 + j][col];
         s2 += H2[r0 + j][col];
+        if (DROP) {
+            const uint32_t b = lastc[(size_t)(r0 + j) * (SLDW * 4)];
+            q1 += b;
+            q2 += b * b;
+        }
     }
-    const uint32_t n = n_w * n_h;
+    const uint32_t n = n_w * n_h, n_k = (n_w - 1) * n_h;
     // searched windows: x in [1, r_w - n_w], y in [1, r_h - n_h]  (src/ncc.rs:279-282, src/ncc.cpp:302)
-    const bool x_ok = x >= 1 && x + n_w <= r_w;
+    const bool x_ok = x >= 1 && x + n_w <= r_w, xk_ok = x >= 1 && x + n_w - 1 <= r_w;
     const uint32_t ya = y0 + r0;
-    int32_t *out_p = negL + ((size_t)page * Lrows + ya) * Lpitch + x;
     // M-tile marks: one store per 16-lane group and window row, decided by ballot (blank paper is never scanned;
     // the reference prunes it too, src/ncc.rs:280-301).  Row y of the image is tile row y - 1.
     const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
@@ -141,29 +163,40 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 nz = V != 0;
                 Vf = (float)V;
             }
-            // raw v_sqrt_f32 (1 ulp): with the conversion and the product the relative error stays < 2.5e-7, i.e.
-            // < 1 for |L| < 4e6; the -2 absorbs it
-            float Lf = __builtin_floorf(kq * __builtin_amdgcn_sqrtf(Vf)) - 2.0f;
-            Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-            const bool emit = x_ok && y >= 1 && y + n_h <= r_h && nz;
-            const int32_t out = emit ? -(int32_t)Lf : -REJECT;
-            const uint64_t lm = __builtin_amdgcn_ballot_w64(emit);
-            if (mark && mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
-            if (NORMS) {
-                // norm = sqrt(V / n) as f16, rounded TOWARDS ZERO (v_cvt_pkrtz): the stored value is a lower bound of the norm,
-                // at most 2^-10 (+ 4 * 2^-24 from the f32 conversion, product with the rounded 1/n and 1-ulp sqrt) below it;
-                // norms lie in [sqrt(1/512), 2886]: always normal f16 numbers.  2 B per window and class instead of 4.
-                float nrm = __builtin_amdgcn_sqrtf(Vf * kq);
-                if (mark && !emit) nrm = -nrm;  // sign = "never emits here"; |value| stays the norm (-0 for a flat window)
-                const auto h2 = __builtin_amdgcn_cvt_pkrtz(nrm, 0.f);
-                reinterpret_cast<uint16_t *>(negL)[((size_t)page * Lrows + y) * Lpitch + x] = (uint16_t)(__builtin_bit_cast(uint32_t, h2) & 0xffffu);
-            } else {
-                out_p[(size_t)k * Lpitch] = out;
+            const bool y_ok = y >= 1 && y + n_h <= r_h;
+            const uint32_t s_k = s - q1, s2_k = s2 - q2;  // the kept box (DROP)
+            const float Wf = DROP ? (float)dropped_column_W(n_k, n_h, s_k, q1, q2) : 0.f;
+            const bool emit = x_ok && y_ok && nz;
+            bool any = emit;
+            const size_t idx = ((size_t)page * Lrows + y) * Lpitch + x;
+            stats_store<OUT>(A, idx, emit, threshold_f32(A.p, Vf, Wf));
+            if (PAIR) {  // the kept box as a size class of its own: (n_w - 1) x n_h, nothing dropped
+                bool nzk;
+                float Vkf;
+                if (SMALLN) {
+                    const uint32_t Vk = n_k * s2_k - s_k * s_k;
+                    nzk = Vk != 0;
+                    Vkf = (float)Vk;
+                } else {
+                    const uint64_t Vk = (uint64_t)n_k * s2_k - (uint64_t)s_k * s_k;
+                    nzk = Vk != 0;
+                    Vkf = (float)Vk;
+                }
+                const bool emit_k = xk_ok && y_ok && nzk;
+                any |= emit_k;
+                stats_store<OUT>(B, idx, emit_k, threshold_f32(B.p, Vkf, 0.f));
             }
+            const uint64_t lm = __builtin_amdgcn_ballot_w64(any);
+            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
         }
         if (k + 1 < PER) {  // slide down one row
             s += H[r0 + k + n_h][col] - H[r0 + k][col];
             s2 += H2[r0 + k + n_h][col] - H2[r0 + k][col];
+            if (DROP) {
+                const uint32_t bi = lastc[(size_t)(r0 + k + n_h) * (SLDW * 4)], bo = lastc[(size_t)(r0 + k) * (SLDW * 4)];
+                q1 += bi - bo;
+                q2 += bi * bi - bo * bo;
+            }
         }
     }
 }
@@ -265,12 +298,15 @@ __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 // host side
 
-// Quantise the bank (see the header comment).  `dense` holds the class-ordered dense needles.
+// Size classes -> K layouts, kept widths, super-classes, bank offsets (host only).
 void layout_supers(focr_ctx *c) {
+    // Column drop (mfma_common.h, "threshold planes"): a class of width 4k + 1 (9, 13) gives its last column to the bound
+    // and takes the next narrower K layout — BASELINE configs[1]'s 9x15 templates: 2 K-steps instead of 3.
+    for (SizeClass &sc : c->classes) sc.keep_w = (c->column_drop && !sc.tall && (sc.n_w == 9 || sc.n_w == 13)) ? sc.n_w - 1 : sc.n_w;
     // K layout per class (mfma_common.h).  Narrow classes ride the 12-byte-row layout whenever a 9..12-wide
     // class exists, so that all of them share one set of A fragments (one "super-class", one kernel pass).
     bool any_mid = false;
-    for (const SizeClass &sc : c->classes) any_mid |= (!sc.tall && sc.n_w >= 9 && sc.n_w <= 12);
+    for (const SizeClass &sc : c->classes) any_mid |= (!sc.tall && sc.keep_w >= 9 && sc.keep_w <= 12);
     c->supers.clear();
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
@@ -279,7 +315,7 @@ void layout_supers(focr_ctx *c) {
             sc.k_groups = sc.n_tiles16 = 0;
             continue;
         }
-        sc.layout = sc.n_w >= 13 ? LAYOUT_W16 : (any_mid ? LAYOUT_W12 : LAYOUT_W8);
+        sc.layout = sc.keep_w >= 13 ? LAYOUT_W16 : (any_mid ? LAYOUT_W12 : LAYOUT_W8);
         if (sc.layout == LAYOUT_W8) sc.k_groups = ((sc.n_h + 1) / 2 + 3) / 4 * 4;   // 2 rows per group
         else if (sc.layout == LAYOUT_W12) sc.k_groups = (sc.n_h + 15) / 16 * 12;    // 16 rows -> 12 groups (3 K-steps)
         else sc.k_groups = (sc.n_h + 3) / 4 * 4;                                    // 1 row per group
@@ -312,29 +348,35 @@ void layout_supers(focr_ctx *c) {
     }
 }
 
-int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
+// Quantise the bank (header comment; column drop: mfma_common.h).  `dense` holds the class-ordered dense needles.  Host only:
+// fills the per-lane MFMA operand image of every class, the class-ordered template ids (~0 = dead / padding) and
+// c->mfma_c_scale / mfma_e_max / mfma_rho_max.
+int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of) {
     layout_supers(c);
     size_t q_bytes = 0, tg_entries = 0;
     for (const SuperClass &su : c->supers) {
         q_bytes += (size_t)su.n_tiles * su.ksteps * 1024;
         tg_entries += (size_t)su.n_tiles * 16;
     }
-    std::vector<int8_t> qbank(q_bytes, 0);
-    std::vector<uint32_t> tglobal(tg_entries, 0xffffffffu), order_of(c->n_templates, 0);
+    qbank.assign(q_bytes, 0);
+    tglobal.assign(tg_entries, 0xffffffffu);
+    order_of.assign(c->n_templates, 0);
     c->mfma_c_scale.clear();
     c->mfma_e_max.clear();
+    c->mfma_rho_max.clear();
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
-        const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4;
+        const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4, kw = sc.keep_w, n_k = kw * sc.n_h;
         if (sc.tall) {
             for (uint32_t i = 0; i < sc.n_templates; i++) order_of[c->h_tconst[sc.first + i].index] = sc.first + i;
             c->mfma_c_scale.push_back(1.0);
             c->mfma_e_max.push_back(0.0);
+            c->mfma_rho_max.push_back(0.0);
             continue;
         }
-        // bank-wide scale: 126 / max |b - mean| / norm_n over live templates
-        double max_ratio = 0.0;
-        std::vector<double> norm_n(sc.n_templates, 0.0), mean(sc.n_templates, 0.0);
+        // unit mean-centred templates beta; on the kept columns beta' = beta + sigma / n_k (sigma = the dropped column's sum)
+        std::vector<std::vector<double>> bp(sc.n_templates);
+        double max_ratio = 0.0, rho_max = 0.0;
         for (uint32_t i = 0; i < sc.n_templates; i++) {
             const TemplateConst &tc = c->h_tconst[sc.first + i];
             order_of[tc.index] = sc.first + i;
@@ -344,37 +386,48 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
                 s += nd[p];
                 s2 += (double)nd[p] * nd[p];
             }
-            mean[i] = s / n;
-            double n2 = s2 - s * s / n;
+            const double mean = s / n, n2 = s2 - s * s / n;
             if (!(n2 > 0.0) || !std::isfinite(tc.rnorm_n)) continue;  // constant needle: rnorm_n = inf, never emits
-            norm_n[i] = std::sqrt(n2);
+            const double norm_n = std::sqrt(n2);
             tglobal[sc.tg_offset + i] = tc.index;
-            for (uint32_t p = 0; p < n; p++) max_ratio = std::max(max_ratio, std::fabs(nd[p] - mean[i]) / norm_n[i]);
+            double sigma = 0, rho2 = 0;
+            for (uint32_t j = 0; j < sc.n_h; j++)
+                for (uint32_t x = kw; x < sc.n_w; x++) {
+                    const double b = (nd[j * sc.n_w + x] - mean) / norm_n;
+                    sigma += b;
+                    rho2 += b * b;
+                }
+            rho_max = std::max(rho_max, std::sqrt(rho2));
+            bp[i].resize(n_k);
+            for (uint32_t j = 0; j < sc.n_h; j++)
+                for (uint32_t x = 0; x < kw; x++) {
+                    const double b = (nd[j * sc.n_w + x] - mean) / norm_n + sigma / n_k;
+                    bp[i][j * kw + x] = b;
+                    max_ratio = std::max(max_ratio, std::fabs(b));
+                }
         }
         const double c_scale = max_ratio > 0 ? 126.0 / max_ratio : 1.0;
         double e_max = 0.0;
-        std::vector<double> rk(n);
-        std::vector<int> bq(n);
-        std::vector<uint32_t> idx(n);
+        std::vector<double> rk(n_k);
+        std::vector<int> bq(n_k);
+        std::vector<uint32_t> idx(n_k);
         for (uint32_t i = 0; i < sc.n_templates; i++) {
-            if (norm_n[i] == 0.0) continue;
-            const uint8_t *nd = dense + c->h_needle_off[sc.first + i];
-            const double q = c_scale / norm_n[i];
+            if (bp[i].empty()) continue;
             long sum = 0;
-            for (uint32_t p = 0; p < n; p++) {
-                rk[p] = q * (nd[p] - mean[i]);
+            for (uint32_t p = 0; p < n_k; p++) {
+                rk[p] = c_scale * bp[i][p];
                 bq[p] = (int)std::floor(rk[p]);
                 sum += bq[p];
                 idx[p] = p;
             }
             // largest-remainder rounding so that the int8 template sums to exactly zero
-            const long deficit = -sum;  // sum(rk) = 0 in exact arithmetic, so 0 <= deficit <= n
-            if (deficit < 0 || deficit > (long)n) return fail(c, FOCR_ERR_INVALID, "mfma bank: rounding deficit out of range");
+            const long deficit = -sum;  // sum(rk) = 0 in exact arithmetic, so 0 <= deficit <= n_k
+            if (deficit < 0 || deficit > (long)n_k) return fail(c, FOCR_ERR_INVALID, "mfma bank: rounding deficit out of range");
             std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return rk[a] - bq[a] > rk[b] - bq[b]; });
             for (long d = 0; d < deficit; d++) bq[idx[d]] += 1;
             double e2 = 0;
             long check = 0;
-            for (uint32_t p = 0; p < n; p++) {
+            for (uint32_t p = 0; p < n_k; p++) {
                 if (bq[p] > 127 || bq[p] < -127) return fail(c, FOCR_ERR_INVALID, "mfma bank: quantised template out of int8 range");
                 double e = rk[p] - bq[p];
                 e2 += e * e;
@@ -385,21 +438,26 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
             // scatter into the per-lane MFMA B layout: [n-tile][k-step][g][n][16 bytes]
             const uint32_t nt = i / 16, nn = i % 16;
             for (uint32_t j = 0; j < sc.n_h; j++)
-                for (uint32_t x = 0; x < sc.n_w; x++) {
+                for (uint32_t x = 0; x < kw; x++) {
                     uint32_t ks, g, byte;
                     kgroup_of(sc.layout, j, x, &ks, &g, &byte);
-                    qbank[sc.q_offset + ((size_t)(nt * ksteps + ks) * 64 + g * 16 + nn) * 16 + byte] = (int8_t)bq[j * sc.n_w + x];
+                    qbank[sc.q_offset + ((size_t)(nt * ksteps + ks) * 64 + g * 16 + nn) * 16 + byte] = (int8_t)bq[j * kw + x];
                 }
         }
         c->mfma_c_scale.push_back(c_scale);
         c->mfma_e_max.push_back(e_max);
+        c->mfma_rho_max.push_back(rho_max);
     }
+    return FOCR_OK;
+}
+
+int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
+    std::vector<int8_t> qbank;
+    std::vector<uint32_t> tglobal, order_of;
+    if (int rc = quantise_bank(c, dense, qbank, tglobal, order_of)) return rc;
     FOCR_HIP(c, hipMalloc((void **)&c->d_qbank, qbank.size() ? qbank.size() : 16));
     FOCR_HIP(c, hipMemcpy(c->d_qbank, qbank.data(), qbank.size(), hipMemcpyHostToDevice));
-    // the two-stage prefilter's data (lowrank.hip) is built on first use: ensure_lowrank()
-    c->h_dense.assign(dense, dense + (c->h_needle_off.empty() ? 0 : c->h_needle_off.back() + c->h_tconst.back().n_w * c->h_tconst.back().n_h));
-    c->lr_built = false;
-    FOCR_HIP(c, hipMalloc((void **)&c->d_tglobal, tglobal.size() * 4));
+    FOCR_HIP(c, hipMalloc((void **)&c->d_tglobal, tglobal.size() ? tglobal.size() * 4 : 16));
     FOCR_HIP(c, hipMemcpy(c->d_tglobal, tglobal.data(), tglobal.size() * 4, hipMemcpyHostToDevice));
     // verify operand: every template as n_h rows of 16 bytes (zero padded), class-ordered
     std::vector<uint8_t> n16;
@@ -421,62 +479,60 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     return FOCR_OK;
 }
 
-// Two-stage prefilter data (lowrank.hip), per super-class that qualifies; built when FOCR_PREFILTER_TWO_STAGE first scans
-// (tens of ms of host work per bank that the default path should not pay at every bank upload).
-static int ensure_lowrank(focr_ctx *c) {
-    if (c->lr_built) return FOCR_OK;
-    std::vector<int8_t> basis;
-    std::vector<uint16_t> gb;
-    for (SuperClass &su : c->supers) build_lowrank(c, su, c->h_dense.data(), basis, gb);
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->d_lr_basis) (void)hipFree(c->d_lr_basis);
-    if (c->d_lr_g) (void)hipFree(c->d_lr_g);
-    c->d_lr_basis = nullptr;
-    c->d_lr_g = nullptr;
-    FOCR_HIP(c, hipMalloc((void **)&c->d_lr_basis, basis.size() ? basis.size() : 16));
-    FOCR_HIP(c, hipMemcpy(c->d_lr_basis, basis.data(), basis.size(), hipMemcpyHostToDevice));
-    FOCR_HIP(c, hipMalloc((void **)&c->d_lr_g, gb.size() ? gb.size() * 2 : 16));
-    FOCR_HIP(c, hipMemcpy(c->d_lr_g, gb.data(), gb.size() * 2, hipMemcpyHostToDevice));
-    c->lr_built = true;
-    return FOCR_OK;
-}
-
-template <int NDW>
-static void launch_stats(focr_ctx *c, const SizeClass &sc, double kappa, int32_t *negL, uint32_t Lpitch, uint32_t Lrows,
-                         uint8_t *live, uint32_t mtx, uint32_t n_rows) {
-    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
-    // kq = kappa / sqrt(n), rounded toward -inf so that the f32 product never overshoots the true threshold
-    const double kq_d = kappa / std::sqrt((double)(sc.n_w * sc.n_h));
+// Threshold parameters of one size class for one scan (mfma_common.h, "threshold planes"): kq towards -inf, crk upwards.
+PlaneParams plane_params(const focr_ctx *c, size_t k, double thr_d) {
+    const SizeClass &sc = c->classes[k];
+    const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k], rho = c->mfma_rho_max[k];
+    const double n = (double)sc.n_w * sc.n_h, n_k = (double)sc.keep_w * sc.n_h, D = n - n_k;
+    // kappa carries a relative 1e-4 for the f64 roundings of the reference's formula (its similarity differs from the real
+    // number by far less)
+    const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
+    PlaneParams p{};
+    const double kq_d = kappa / std::sqrt(n);
     float kq = (float)kq_d;
     if ((double)kq > kq_d) kq = std::nextafterf(kq, -INFINITY);
     kq = std::nextafterf(kq, -INFINITY);
-    auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
-                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, kq, negL, Lpitch, Lrows, live, mtx,
-                           n_rows, 1u);
-    };
-    if (sc.n_w * sc.n_h <= 256) launch(stats_kernel<NDW, true, false>);
-    else launch(stats_kernel<NDW, false, false>);
+    p.kq = std::isfinite(kq) ? kq : -3.0e38f;  // threshold -inf: everything is a candidate
+    p.crk = 0.f;
+    if (D > 0 && rho > 0) {
+        const double cr_d = cs * rho * (1.0 + 1e-4) / n_k;
+        float cr = (float)cr_d;
+        if ((double)cr < cr_d) cr = std::nextafterf(cr, INFINITY);
+        p.crk = std::nextafterf(std::nextafterf(cr, INFINITY), INFINITY);  // also covers a 1-ulp-low square root of W
+    }
+    // |L| <= |kq| * sqrt(V) + crk * sqrt(W) with sqrt(V) <= 127.5 n, sqrt(W) <= 255 n_k sqrt(D); the kernel clamps L to +-1e9
+    const double l_max = std::min(1.0e9, std::fabs((double)p.kq) * 127.5 * n + (double)p.crk * 255.0 * n_k * std::sqrt(std::max(D, 0.0)));
+    int e = 0;
+    std::frexp(std::max(l_max / 32768.0, std::ldexp(1.0, -20)), &e);  // value = m * 2^e, m in [0.5, 1): 2^e >= value
+    p.S = std::ldexp(1.0f, e);
+    p.inv_S = std::ldexp(1.0f, -e);
+    return p;
 }
 
-// window norms of one box (a size class: mark = 1, or the two-stage prefilter's frame: mark = 0) into one plane of d_norms
-static int launch_norms(focr_ctx *c, uint32_t n_w, uint32_t n_h, uint16_t *plane, uint32_t Lpitch, uint32_t Lrows, uint8_t *live, uint32_t mtx,
-                        uint32_t n_rows, uint32_t mark) {
+// one statistics launch: class k (full box), optionally together with its kept box as class `pair` (< 0: none)
+template <int OUT>
+static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out, void *out_pair, uint32_t Lpitch, uint32_t Lrows, uint8_t *live,
+                        uint32_t mtx, uint32_t n_rows) {
+    const SizeClass &sc = c->classes[k];
     dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
-    const float rn = 1.0f / (float)(n_w * n_h);
-    const bool small = n_w * n_h <= 256;
+    StatsOut A{plane_params(c, k, thr_d), out}, B{};
+    if (pair >= 0) B = StatsOut{plane_params(c, (size_t)pair, thr_d), out_pair};
+    const bool drop = sc.keep_w != sc.n_w, small = sc.n_w * sc.n_h <= 256;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
-                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, n_w, n_h, rn, reinterpret_cast<int32_t *>(plane), Lpitch, Lrows, live,
-                           mtx, n_rows, mark);
+        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                           (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows);
     };
-    switch ((n_w + 3) / 4) {
-        case 1: small ? launch(stats_kernel<1, true, true>) : launch(stats_kernel<1, false, true>); break;
-        case 2: small ? launch(stats_kernel<2, true, true>) : launch(stats_kernel<2, false, true>); break;
-        case 3: small ? launch(stats_kernel<3, true, true>) : launch(stats_kernel<3, false, true>); break;
-        case 4: small ? launch(stats_kernel<4, true, true>) : launch(stats_kernel<4, false, true>); break;
+#define STATS_CASE(NDW)                                                                          \
+    case NDW:                                                                                    \
+        if (pair >= 0) small ? launch(stats_kernel<NDW, true, OUT, true, true>) : launch(stats_kernel<NDW, false, OUT, true, true>);       \
+        else if (drop) small ? launch(stats_kernel<NDW, true, OUT, true, false>) : launch(stats_kernel<NDW, false, OUT, true, false>);     \
+        else small ? launch(stats_kernel<NDW, true, OUT, false, false>) : launch(stats_kernel<NDW, false, OUT, false, false>);             \
+        break;
+    switch ((sc.n_w + 3) / 4) {
+        STATS_CASE(1) STATS_CASE(2) STATS_CASE(3) STATS_CASE(4)
         default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported box width");
     }
+#undef STATS_CASE
     FOCR_HIP(c, hipGetLastError());
     return FOCR_OK;
 }
@@ -496,7 +552,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     const size_t L_per_class = c->n_pages * (size_t)Lrows * Lpitch;
     // the per-class int32 threshold tables are only needed by super-classes on the legacy path
     bool need_L = false;
-    for (const SuperClass &su : c->supers) need_L |= su.ksteps > 4 || su.classes.size() > (size_t)LR_MAX_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY;
+    for (const SuperClass &su : c->supers) need_L |= su.ksteps > 4 || su.classes.size() > (size_t)MAX_PLANE_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY;
     const size_t L_bytes = need_L ? L_per_class * c->classes.size() * sizeof(int32_t) : 0;
     if (c->L_bytes < L_bytes) {
         FOCR_HIP(c, hipStreamSynchronize(c->stream));
@@ -508,7 +564,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     }
     int rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 20, c->sub_np * 65536)));
     if (rc) return rc;
-    if (c->prefilter == FOCR_PREFILTER_TWO_STAGE && (rc = ensure_lowrank(c))) return rc;
     size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->sub_np * 131072));
     if (c->estimated) want_cand = std::max(want_cand, c->est_cand);
     hipDeviceProp_t prop;
@@ -563,68 +618,58 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
         if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
         FOCR_HIP(c, hipMemsetAsync(live, 0, tiles_total + 16, c->stream));
-        // which super-classes take the two-stage prefilter (scan_mfma3.hip), and their window-norm planes
-        const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // floats per norm value
+        // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
+        const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // f16 values per plane
         std::vector<int> two(c->supers.size(), 0);
-        std::vector<size_t> norm_off(c->supers.size(), 0);
-        std::vector<uint32_t> norm_nv(c->supers.size(), 0);
-        size_t norm_floats = 0;  // f16 values
+        std::vector<size_t> plane_off(c->supers.size(), 0);
+        size_t plane_vals = 0;
         // two[si]: 0 = legacy path (per-class int32 negL tables, scan_mfma2_kernel: > 4 K-steps or > 4 size classes),
-        //          1 = window norms (one fused statistics pass) + scan_mfma2s_kernel (one stage, roles swapped),
-        //          2 = window norms + scan_mfma3_kernel (two stages)
+        //          1 = f16 threshold planes + scan_mfma2s_kernel (A = templates, B = windows)
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
-            if (!su.mtx || su.ksteps > 4 || su.classes.size() > (size_t)LR_MAX_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY) continue;
-            uint32_t nv = (uint32_t)su.classes.size();
+            if (!su.mtx || su.ksteps > 4 || su.classes.size() > (size_t)MAX_PLANE_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY) continue;
+            const uint32_t nv = (uint32_t)su.classes.size();
             two[si] = 1;
-            // AUTO takes the one-stage prefilter: measured at BASELINE configs[1] the two-stage kernel issues 45 % fewer
-            // MFMA cycles but ends up instruction-issue-bound (3 VALU per 16x16 block for the sign test + the mid stage), 2.33 ms
-            // against 2.30 ms — it is kept as a tested alternative, not as the default
-            if (c->prefilter == FOCR_PREFILTER_TWO_STAGE && su.lr.available && su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0) <= (uint32_t)LR_MAX_VALUES) {
-                two[si] = 2;
-                nv = su.lr.n_cls + (su.lr.frame_class < 0 ? 1 : 0);
-            }
-            norm_nv[si] = nv;
-            norm_off[si] = norm_floats;
-            norm_floats += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernels are instantiated for 1 / 2 / 4 values
+            plane_off[si] = plane_vals;
+            plane_vals += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernel is instantiated for 1 / 2 / 4 values
         }
-        if (c->norms_bytes < norm_floats * 2) {
+        if (c->planes_bytes < plane_vals * 2) {
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
-            if (c->d_norms) (void)hipFree(c->d_norms);
-            c->d_norms = nullptr;
-            c->norms_bytes = 0;
-            if (hipMalloc((void **)&c->d_norms, norm_floats * 2) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(norms) failed");
-            c->norms_bytes = norm_floats * 2;
+            if (c->d_planes) (void)hipFree(c->d_planes);
+            c->d_planes = nullptr;
+            c->planes_bytes = 0;
+            if (hipMalloc((void **)&c->d_planes, plane_vals * 2) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc(planes) failed");
+            c->planes_bytes = plane_vals * 2;
         }
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            if (two[si]) {  // window norms: one plane per size class (+ the frame's, if no class has its box)
-                for (uint32_t v = 0; v < norm_nv[si]; v++) {
-                    const bool is_class = v < su.classes.size();
-                    const uint32_t bw = is_class ? c->classes[su.classes[v]].n_w : su.lr.frame_w;
-                    const uint32_t bh = is_class ? c->classes[su.classes[v]].n_h : su.lr.frame_h;
-                    if ((rc = launch_norms(c, bw, bh, c->d_norms + norm_off[si] + (size_t)v * plane, Lpitch, Lrows, live + su.live_offset, su.mtx, su.n_rows,
-                                           is_class ? 1u : 0u)))
-                        return rc;
-                }
-            } else {
-                for (uint32_t k : su.classes) {
-                    const SizeClass &sc = c->classes[k];
-                    if (sc.n_w >= c->r_w || sc.n_h >= c->r_h) continue;
-                    const double cs = c->mfma_c_scale[k], em = c->mfma_e_max[k];
-                    const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
-                    int32_t *negL = c->d_L + k * L_per_class;
-                    uint8_t *lv = live + su.live_offset;
-                    switch (sc.ndw) {
-                        case 1: launch_stats<1>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                        case 2: launch_stats<2>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                        case 3: launch_stats<3>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                        case 4: launch_stats<4>(c, sc, kappa, negL, Lpitch, Lrows, lv, su.mtx, su.n_rows); break;
-                        default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported size class");
+            uint8_t *lv = live + su.live_offset;
+            std::vector<char> done(su.classes.size(), 0);
+            for (size_t v = 0; v < su.classes.size(); v++) {
+                if (done[v]) continue;
+                const size_t k = su.classes[v];
+                const SizeClass &sc = c->classes[k];
+                if (!two[si] && (sc.n_w >= c->r_w || sc.n_h >= c->r_h)) continue;  // nothing searchable: its tiles are skipped below
+                // a class whose last column is dropped computes its kept box's statistics anyway: if that box is a size class
+                // of this pass too, both come out of one launch
+                int pair = -1;
+                size_t pv = 0;
+                if (sc.keep_w != sc.n_w)
+                    for (size_t u = 0; u < su.classes.size(); u++) {
+                        const SizeClass &o = c->classes[su.classes[u]];
+                        if (u != v && !done[u] && o.n_w == sc.keep_w && o.n_h == sc.n_h && o.keep_w == o.n_w) pair = (int)su.classes[u], pv = u;
                     }
-                    FOCR_HIP(c, hipGetLastError());
+                if (two[si]) {
+                    uint16_t *base = c->d_planes + plane_off[si];
+                    rc = launch_stats<1>(c, k, pair, thr_d, base + v * plane, pair >= 0 ? base + pv * plane : nullptr, Lpitch, Lrows, lv, su.mtx, su.n_rows);
+                } else {
+                    rc = launch_stats<0>(c, k, pair, thr_d, c->d_L + k * L_per_class, pair >= 0 ? c->d_L + (size_t)pair * L_per_class : nullptr, Lpitch, Lrows, lv,
+                                         su.mtx, su.n_rows);
                 }
+                if (rc) return rc;
+                done[v] = 1;
+                if (pair >= 0) done[pv] = 1;
             }
             const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->sub_np);
             hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
@@ -649,7 +694,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx) continue;
-            const uint32_t chunk_tiles = two[si] == 2 ? mfma3_chunk_tiles(su.ksteps) : mfma2_chunk_tiles(su.ksteps);
+            const uint32_t chunk_tiles = mfma2_chunk_tiles(su.ksteps);
             uint32_t t0 = 0;
             while (t0 < su.n_tiles) {
                 MfmaLaunch L{};
@@ -664,7 +709,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.super_index = (uint32_t)si;
                 const uint32_t t_limit = std::min(su.n_tiles, t0 + chunk_tiles);
                 uint32_t t1 = t0;
-                Mfma3Args A3{};
+                PlaneArgs A3{};
                 for (size_t i = 0; i < su.classes.size() && L.segs.n < (uint32_t)MAX_SEGS; i++) {
                     const SizeClass &sc = c->classes[su.classes[i]];
                     const uint32_t cb = su.tile_first[i], ce = cb + sc.n_tiles16;
@@ -677,16 +722,9 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                         }
                         break;
                     }
-                    {  // the exact-taps stage's threshold scale of the segment's class (two-stage kernel: L = floor(kq * norm) - 2)
-                        const double cs = c->mfma_c_scale[su.classes[i]], em = c->mfma_e_max[su.classes[i]];
-                        const double kappa = cs * thr_d - em - 1e-4 * (cs * (1.0 + std::fabs(thr_d)) + em);
-                        float kq = (float)kappa;
-                        if ((double)kq > kappa) kq = std::nextafterf(kq, -INFINITY);
-                        kq = std::nextafterf(kq, -INFINITY);
-                        A3.kq[L.segs.n] = std::isfinite(kq) ? kq : -3.0e38f;
-                        A3.seg_value[L.segs.n] = (uint32_t)i;
-                        A3.seg_full[L.segs.n] = (su.layout == LAYOUT_W12 && sc.n_w <= 8) ? 0u : 1u;  // mfma_common.h: K layouts
-                    }
+                    A3.S[L.segs.n] = plane_params(c, su.classes[i], thr_d).S;  // the unit of the class's plane
+                    A3.seg_value[L.segs.n] = (uint32_t)i;
+                    A3.seg_full[L.segs.n] = (su.layout == LAYOUT_W12 && sc.keep_w <= 8) ? 0u : 1u;  // mfma_common.h: K layouts
                     MfmaSeg &sg = L.segs.s[L.segs.n++];
                     sg.negL = c->d_L + su.classes[i] * L_per_class;
                     sg.tile_end = e - t0;
@@ -706,28 +744,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
                 if (c->scan_queues_used >= MAX_SCAN_QUEUES) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many scan passes for one call (bank too large)");
                 L.queue = c->d_counter + COUNTER_WORDS + (size_t)(c->scan_queues_used++) * QUEUE_XCDS * QUEUE_STRIDE;
-                if (two[si] == 1) {
-                    A3.norms = c->d_norms + norm_off[si];
-                    A3.norm_stride = plane;
-                    A3.nv = norm_nv[si];
-                    A3.n_cls = (uint32_t)su.classes.size();
+                if (two[si]) {
+                    A3.planes = c->d_planes + plane_off[si];
+                    A3.stride = plane;
+                    A3.nv = (uint32_t)su.classes.size();
                     if ((rc = dispatch_mfma_v2s(c, L, A3, cus))) return rc;
-                } else if (two[si] == 2) {
-                    A3.norms = c->d_norms + norm_off[si];
-                    A3.norm_stride = plane;
-                    A3.nv = norm_nv[si];
-                    A3.n_cls = su.lr.n_cls;
-                    A3.frame_value = su.lr.frame_class >= 0 ? (uint32_t)su.lr.frame_class : su.lr.n_cls;
-                    A3.inv_lambda = su.lr.inv_lambda;
-                    // the reference emits iff sim > thr; thr_eff leaves 1e-4 for the f64 roundings of its formula, thr_lo
-                    // another 2^-20 for the f32 norm on the device.  Similarities live in [-1, 1]: below -2 nothing changes.
-                    const double te = std::max(thr_d - 1e-4 * (1.0 + std::fabs(thr_d)), -2.0);
-                    const double tl = te >= 0 ? te * (1.0 - std::ldexp(1.0, -20)) : te * (1.0 + std::ldexp(1.0, -20));
-                    A3.thr_lo = (float)tl;
-                    if ((double)A3.thr_lo > tl) A3.thr_lo = std::nextafterf(A3.thr_lo, -INFINITY);
-                    A3.theta_add = A3.thr_lo < 0.f ? 0xffffu : 0u;
-                    if ((rc = dispatch_mfma_v3(c, L, A3, c->d_lr_basis + su.lr.basis_offset, (const uint16_t *)((const uint8_t *)c->d_lr_g + su.lr.g_offset) + (size_t)t0 * 512, cus)))
-                        return rc;
                 } else if ((rc = dispatch_mfma_v2(c, L, cus))) {
                     return rc;
                 }

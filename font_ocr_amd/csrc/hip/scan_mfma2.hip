@@ -7,8 +7,8 @@
 // per workgroup, so a kernel has exactly one barrier; there is no per-tile fill/drain.  One workgroup per CU.
 //
 //   scan_mfma2s_kernel  the default (<= 4 K-steps, <= 4 size classes per pass): A = templates, B = windows, the C-in of a
-//                       lane is the threshold of its own window, formed in registers from f16 window norms; 16 waves x 4
-//                       M-tiles per CU, 128 VGPRs.
+//                       lane is the threshold of its own window, formed in registers from the f16 threshold planes; 16
+//                       waves x 4 M-tiles per CU, 128 VGPRs.
 //   scan_mfma2_kernel   round 1's form (A = windows, int32 negL rows re-loaded per size class), kept for 5..8 K-steps and
 //                       as a cross-check (FOCR_PREFILTER_LEGACY); 8 waves x 4..8 M-tiles for the long layouts.
 #include <algorithm>
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 // ---------------------------------------------------------------------------------------------
 // The same one-stage prefilter with the operand roles swapped: (A = templates, B = windows), so D[template][window] puts
 // window px + r on lane (r, g) for all four accumulator registers.  The C-in of a lane is then the threshold of its OWN
-// window: one f32 norm per size class and M-tile stays in a register for the whole item (stats_lr_kernel's planar
-// norms, scan_mfma3.hip) and the int32 threshold -(floor(kq * norm) - 2) is formed from it once per item — no per-class
-// int32 table, no reload of C-in rows in the middle of the N-tile loop when the size class changes.
+// window: one f16 threshold-plane value per size class and M-tile (mfma_common.h) stays in a register for the whole item
+// and the int32 C-in -(floor(S * v) - 2) is formed from it once per item — no per-class int32 table, no reload of C-in rows
+// in the middle of the N-tile loop when the size class changes.
 #ifndef FOCR_V2S_NW
 #define FOCR_V2S_NW 16  // waves per workgroup (one workgroup per CU); experiment builds: make hip EXTRA=-DFOCR_V2S_NW=12
 #endif
@@ -217,7 +217,7 @@ template <int KSTEPS, int RPG, int MT, int NW, int NV>
 __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
-    const Mfma3Args P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
+    const PlaneArgs P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
     unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
@@ -234,13 +234,13 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 
     const uint32_t total_mt = *live_count;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    float kq_of_value[NV];  // threshold scale per norm value (= per size class of the super-class)
+    float S_of_value[NV];  // unit of the threshold plane per value (= per size class of the super-class)
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-        kq_of_value[v] = 0.f;
+        S_of_value[v] = 1.f;
 #pragma unroll
-        for (int sg = 0; sg < (int)LR_MAX_CLASSES; sg++)
-            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) kq_of_value[v] = P.kq[sg];
+        for (int sg = 0; sg < MAX_PLANE_VALUES; sg++)
+            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) S_of_value[v] = P.S[sg];
     }
 
     ItemTaker take;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
             py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
             pp[mt] = (uint32_t)(e >> 32);
         }
-        float nrm[MT][NV];  // norms of the lane's own window px + r, one per size class
+        float nrm[MT][NV];  // threshold-plane values of the lane's own window px + r, one per size class
 #ifdef FOCR_V2S_VARIANTS
         if (variant & 8) {
 #pragma unroll
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 #endif
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const uint16_t *np = P.norms + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+            const uint16_t *np = P.planes + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
 #pragma unroll
-            for (int v = 0; v < NV; v++) nrm[mt][v] = (float)__builtin_bit_cast(_Float16, np[(size_t)v * P.norm_stride]);  // f16, a lower bound
+            for (int v = 0; v < NV; v++) nrm[mt][v] = f16_bits_to_f32(np[(size_t)v * P.stride]);  // L / S rounded towards -inf; +inf = never
         }
         // K-step-major issue order: the N-tile loop's first MFMAs need K-step 0 of all M-tiles
 #pragma unroll
@@ -322,17 +322,14 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the item's loads (the ticket may stay outstanding)
         PROF2(1)
 #endif
-        // C-in of the lane's own window per size class: -(floor(kq * norm_c) - 2) (scan_mfma.hip: conservative for
-        // |L| < 4e6), -REJECT where the class never emits (the statistics kernel flags that in the sign) or past the enumeration
+        // C-in of the lane's own window per size class (prefilter_cin, mfma_common.h; a window the class never emits at holds
+        // +inf, which comes out as an unreachable threshold), -REJECT past the enumeration
         int cin[MT][NV];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                const float nc = nrm[mt][v];
-                float Lf = __builtin_floorf(kq_of_value[v] * nc) - 2.0f;
-                Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-                cin[mt][v] = (nc > 0.f && pv[mt]) ? -(int)Lf : -REJECT;
+                cin[mt][v] = pv[mt] ? prefilter_cin(S_of_value[v], nrm[mt][v]) : -REJECT;
             }
         v4i bf[KSTEPS];
 #pragma unroll
@@ -429,7 +426,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 }
 
 template <int KSTEPS, int RPG, int NV>
-static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
+static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, unsigned n_cus) {
     constexpr int MT = 4, NW = FOCR_V2S_NW;
     const uint32_t n_tiles16 = L.n_tiles16;
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
@@ -461,7 +458,7 @@ extern "C" int focr_debug_prof2(unsigned long long *out, int reset) {
 }
 #endif
 
-int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const Mfma3Args &A3, unsigned n_cus) {
+int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, unsigned n_cus) {
     const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);
 #define CASE2S(K, R)                                            \
     case (K) * 10 + (R):                                        \

@@ -15,7 +15,7 @@ from .bank import HIT_DTYPE, MATCH_DTYPE
 
 MAX_MATCHES = 1024  # src/ncc.rs:31
 SCAN_MFMA, SCAN_DIRECT, SCAN_RUST = 0, 1, 2
-PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE, PREFILTER_LEGACY = 0, 1, 2, 3
+PREFILTER_AUTO, PREFILTER_ONE_STAGE, PREFILTER_LEGACY = 0, 1, 3
 
 
 class FocrError(RuntimeError):
@@ -171,8 +171,13 @@ class Scanner:
         self._ck(self._lib.focr_scan(self._h, float(threshold), int(cap), int(mode)))
 
     def set_prefilter(self, prefilter):
-        """PREFILTER_AUTO / PREFILTER_ONE_STAGE / PREFILTER_TWO_STAGE (focr_ctx_set_prefilter); results never change."""
+        """PREFILTER_AUTO / PREFILTER_ONE_STAGE / PREFILTER_LEGACY (focr_ctx_set_prefilter); results never change."""
         self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
+
+    def set_column_drop(self, on):
+        """focr_ctx_set_column_drop: bound the last column of 9- / 13-wide classes instead of multiplying it (default on);
+        takes effect at the next set_bank; results never change."""
+        self._ck(self._lib.focr_ctx_set_column_drop(self._h, int(bool(on))))
 
     def set_size_estimates(self, on):
         """focr_ctx_set_size_estimates: repeat scans of one setup queue every phase without host waits (default on)."""

@@ -214,21 +214,24 @@ int focr_sync(focr_ctx_t *ctx);
  * section 5). */
 int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
 
-/* Which MFMA prefilter FOCR_SCAN_MFMA uses.  Results are identical in every mode (both are conservative filters in
- * front of the same exact verify); only the speed differs.
- *   AUTO       two stages where the bank compresses well (glyph banks do), else one
- *   ONE_STAGE  every (window, template) pair pays its n_w*n_h taps in the int8 MFMA (scan_mfma2.hip)
- *   TWO_STAGE  a low-rank bound over ALL templates first (int8 basis + one bf16 MFMA per 16x16 block), the exact-taps
- *              int8 stage only on the blocks it cannot rule out (scan_mfma3.hip); falls back to ONE_STAGE for size
- *              classes it does not cover */
+/* Which MFMA prefilter kernel FOCR_SCAN_MFMA uses.  Results are identical in every mode (conservative filters in front of
+ * the same exact verify); only the speed differs.
+ *   AUTO / ONE_STAGE  scan_mfma2s_kernel: A = templates, B = windows, C-in from the f16 threshold planes (scan_mfma2.hip)
+ *   LEGACY            round 1's kernel (A = windows) with per-class int32 threshold tables — what size classes with more
+ *                     than 4 K-steps always use; selectable as a cross-check
+ * (Value 2 was round 2's two-stage low-rank prefilter: exact, not faster, removed in round 3 — DESIGN.md, dead ends.) */
 enum {
     FOCR_PREFILTER_AUTO = 0,
     FOCR_PREFILTER_ONE_STAGE = 1,
-    FOCR_PREFILTER_TWO_STAGE = 2,
-    FOCR_PREFILTER_LEGACY = 3 /* ONE_STAGE through round 1's kernel and its per-class int32 threshold tables (what size
-                               * classes with more than 4 K-steps always use); kept selectable as a cross-check */
+    FOCR_PREFILTER_LEGACY = 3
 };
 int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
+
+/* Column drop (default on): size classes 9 or 13 px wide give their last column to a Cauchy-Schwarz bound inside the
+ * prefilter threshold instead of multiplying it, and take the next narrower MFMA K layout (9x15 templates: 2 K-steps of 64
+ * bytes instead of 3).  Results are identical either way; off = every column multiplied (cross-check, A/B).  Takes effect at
+ * the next focr_bank_upload. */
+int focr_ctx_set_column_drop(focr_ctx_t *ctx, int on);
 
 /* Result sizes.  Every phase behind the scan kernel takes its element count from device memory.  A scan of the same
  * setup as the context's previous one (same bank, batch geometry, threshold, cap) bounds its buffers by the previous
@@ -345,15 +348,24 @@ int focr_debug_rnorm(focr_ctx_t *ctx, const uint32_t *s, const uint64_t *s2, con
  * without waiting for an overflow. */
 int focr_debug_force_split(focr_ctx_t *ctx, int on);
 
-/* Host model of the two-stage prefilter's bound (no device needed; used by the CPU tests): builds the low-rank data
- * of the bank's first super-class exactly as focr_bank_upload does and evaluates, for n_windows caller-supplied
- * frame-sized ink-high patches (frame_w * frame_h bytes each, row-major), the exact similarity of every template
- * (double; NaN where the reference cannot emit) and the stage-2 value D2 the device computes (the flag is D2 > 0).
- * info[8] = {available, r, n_cls, frame_w, frame_h, mean rho, max rho, inv_lambda}.  windows may be NULL to query
- * info only. */
-int focr_debug_lowrank(const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
-                       size_t needles_len, const uint8_t *windows, size_t n_windows, float threshold,
-                       double *info, double *sim, float *d2);
+/* Host model of the MFMA prefilter's bound (no device needed; used by the CPU tests, tests/test_prefilter_host.py): builds
+ * the quantised bank exactly as focr_bank_upload does and evaluates, for n_windows caller-supplied ink-high patches of
+ * frame_w x frame_h bytes (row-major; every template must fit the frame, its window is the frame's top-left n_w x n_h
+ * box), per (window, template):
+ *   sim[w * n_templates + t]   the exact similarity (double; NaN where the reference cannot emit: zero variance)
+ *   d[w * n_templates + t]     G + C-in as the device forms them: the int8 MFMA sum over the kept columns plus
+ *                              -(floor(S * plane) - 2) with the plane value of the window computed by the statistics
+ *                              kernel's arithmetic (f32, f16 rounded towards -inf); the pair is a candidate iff d > 0
+ * column_drop: as focr_ctx_set_column_drop.  info[4 * k ..] = {c_scale, e_max, rho_max, kept width} of size class k (in
+ * order of first appearance), n_info = capacity of info in doubles. */
+int focr_debug_prefilter(const focr_template_t *templates, size_t n_templates, const uint8_t *needles, size_t needles_len,
+                         int column_drop, const uint8_t *windows, size_t n_windows, uint32_t frame_w, uint32_t frame_h,
+                         float threshold, double *sim, int64_t *d, double *info, size_t n_info);
+
+/* The threshold planes' directed rounding (f32 -> f16 bits towards -inf, |x| < 65504), host flavour, for the CPU tests. */
+void focr_debug_f16_down(const float *x, size_t n, uint16_t *out);
+/* The same rounding as the device performs it (the GPU tests compare the two bit for bit). */
+int focr_debug_f16_down_device(focr_ctx_t *ctx, const float *x, size_t n, uint16_t *out);
 
 #ifdef __cplusplus
 }

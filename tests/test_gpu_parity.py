@@ -5,16 +5,18 @@ import pytest
 
 from font_ocr_amd import synth_page, synth_pages
 from font_ocr_amd.bank import SYNTH_SEED_BASE
-from font_ocr_amd.searcher import PREFILTER_AUTO, PREFILTER_LEGACY, PREFILTER_ONE_STAGE, PREFILTER_TWO_STAGE, SCAN_DIRECT, SCAN_MFMA, Scanner, Searcher, text_of
+from font_ocr_amd.searcher import PREFILTER_AUTO, PREFILTER_LEGACY, PREFILTER_ONE_STAGE, SCAN_DIRECT, SCAN_MFMA, Scanner, Searcher, text_of
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-# the exact v_dot4 path and the MFMA path with each of its prefilters (one stage: every pair pays its taps in int8;
-# two stages: low-rank bound first, scan_mfma3.hip) — all three must reproduce the reference lists bit for bit
-MFMA1, MFMA2, MFMA0 = (SCAN_MFMA, PREFILTER_ONE_STAGE), (SCAN_MFMA, PREFILTER_TWO_STAGE), (SCAN_MFMA, PREFILTER_LEGACY)
-MODES = [pytest.param(SCAN_DIRECT, id="direct"), pytest.param((SCAN_MFMA, PREFILTER_ONE_STAGE), id="mfma1"),
-         pytest.param((SCAN_MFMA, PREFILTER_TWO_STAGE), id="mfma2")]
+# The exact v_dot4 path and the MFMA path (int8 prefilter + exact verify) must reproduce the reference lists bit for bit.
+# MFMA1 = the default kernel (f16 threshold planes), MFMA0 = round 1's kernel with int32 threshold tables; FULL = MFMA1 with
+# every template column multiplied (focr_ctx_set_column_drop(0): 9- / 13-wide classes on their wider K layout) — the
+# parametrised matrix runs direct + MFMA1, the other two forms are crossed in the full-size, geometry, layout and fuzz tests.
+MFMA1, MFMA0 = (SCAN_MFMA, PREFILTER_ONE_STAGE), (SCAN_MFMA, PREFILTER_LEGACY)
+FULL = "mfma1, no column drop"
+MODES = [pytest.param(SCAN_DIRECT, id="direct"), pytest.param(MFMA1, id="mfma1")]
 
 
 @pytest.fixture(scope="module")
@@ -22,6 +24,23 @@ def scanner():
     s = Scanner(0)
     yield s
     s.close()
+
+
+@pytest.fixture(autouse=True)
+def _column_drop_back_on(request):
+    yield
+    if "scanner" in request.fixturenames:
+        request.getfixturevalue("scanner").set_column_drop(True)
+
+
+def _scan(scanner, bank, thr, cap, mode):
+    """scanner.scan for a mode of the matrix above; FULL re-uploads the bank without the column drop (and leaves it so: keep
+    FULL last in a loop, or upload the bank again)."""
+    if mode == FULL:
+        scanner.set_column_drop(False)
+        scanner.set_bank(bank)
+        mode = MFMA1
+    scanner.scan(thr, cap, mode)
 
 
 def _csr_to_lists(offsets, m, n_pages, T):
@@ -59,6 +78,22 @@ def test_device_f64_divide_sqrt_are_correctly_rounded(scanner):
         want = 1.0 / np.sqrt(s2.astype(np.float64) - (s.astype(np.uint64) * s.astype(np.uint64)).astype(np.float64) / n.astype(np.float64))
     same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), f"{(~same).sum()} of {cnt} differ"
+
+
+def test_threshold_plane_rounding_device_equals_host(scanner):
+    """f32 -> f16 towards -inf: the device flavour (v_cvt_pkrtz + fix-up) and the host flavour the CPU tests model the
+    prefilter with (mfma_common.h, f16_down) agree bit for bit, and never round up."""
+    import ctypes as C
+
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.normal(0, 1, 400000) * 10.0 ** rng.integers(-9, 5, 400000),
+                        [0.0, -0.0, 1.0, -1.0, 65000.0, -65000.0, 6e-8, -6e-8, 1e-9, -1e-9, 2.0 ** -14, -(2.0 ** -14), 2.0 ** -24, -(2.0 ** -25)]]).astype(np.float32)
+    x = np.ascontiguousarray(x[np.abs(x) < 65000])
+    host, dev = np.zeros(len(x), np.uint16), np.zeros(len(x), np.uint16)
+    scanner._lib.focr_debug_f16_down(x.ctypes.data_as(C.c_void_p), len(x), host.ctypes.data_as(C.c_void_p))
+    scanner._ck(scanner._lib.focr_debug_f16_down_device(scanner._h, x.ctypes.data_as(C.c_void_p), len(x), dev.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(host, dev), x[host != dev][:8]
+    assert (dev.view(np.float16).astype(np.float64) <= x.astype(np.float64)).all()
 
 
 def test_compat_symbols_on_golden_vectors(kernel_cases):
@@ -192,16 +227,22 @@ def test_full_size_c2_properties(scanner, bank_x2):
     scanner.set_bank(bank_x2)
     scanner.set_pages(pages)
     res = {}
-    kernel_of = {MFMA0: "scan_mfma2_kernel", MFMA1: "scan_mfma2s_kernel", MFMA2: "scan_mfma3_kernel"}
-    for mode in (SCAN_DIRECT, MFMA0, MFMA1, MFMA2):
-        scanner.scan(0.8, 1024, mode)
+    # both size classes (8x15, 9x15 with its ninth column bounded) in one pass of 2 K-steps; every column multiplied: 3
+    kernel_of = {MFMA0: "scan_mfma2_kernel<2,2,", MFMA1: "scan_mfma2s_kernel<2,2,", FULL: "scan_mfma2s_kernel<3,3,"}
+    cand = {}
+    for mode in (SCAN_DIRECT, MFMA0, MFMA1, FULL):
+        _scan(scanner, bank_x2, 0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
+        cand[mode] = scanner.counters()["candidates"]
         if mode != SCAN_DIRECT:
-            assert [li["name"].split("<")[0] for li in scanner.launches()] == [kernel_of[mode]]
-    for mode in (MFMA0, MFMA1, MFMA2):
+            names = [li["name"] for li in scanner.launches()]
+            assert len(names) == 1 and names[0].startswith(kernel_of[mode]), names
+    for mode in (MFMA0, MFMA1, FULL):
         assert np.array_equal(res[SCAN_DIRECT][0], res[mode][0])
         assert res[SCAN_DIRECT][2].tobytes() == res[mode][2].tobytes()
-    res[SCAN_MFMA] = res[MFMA2]
+    # the price of the bound: more candidates for verify to reject, the same hits (about 1.2 x)
+    assert cand[FULL] < cand[MFMA1] < 1.5 * cand[FULL], cand
+    res[SCAN_MFMA] = res[FULL]
     scanner.process_hits(0.95, 5)
     lines = scanner.lines()
     ok = tot = 0
@@ -247,25 +288,27 @@ def test_c3_geometry_1200x1600_vs_reference(scanner, bank_x2y2):
     pages = synth_pages(bank_x2y2, 4, r_w, r_h, first=3000)
     scanner.set_bank(bank_x2y2)
     scanner.set_pages(pages)
-    scanner.scan(0.8, 1024, MFMA2)
+    scanner.scan(0.8, 1024, MFMA1)
     res4 = (scanner.counts().copy(),) + scanner.matches()
-    assert all(li["name"].startswith("scan_mfma3") for li in scanner.launches()) and len(scanner.launches()) >= 2  # bank chunks
+    assert all(li["name"].startswith("scan_mfma2s") for li in scanner.launches())
     _assert_equal_ref_batch(res4, pages, bank_x2y2, 0.8, 1024)
     assert res4[0].sum() > 400_000  # dense text: ~1e5 raw hits per page
-    for mode in (SCAN_DIRECT, MFMA1, MFMA0):
-        scanner.scan(0.8, 1024, mode)
+    for mode in (SCAN_DIRECT, MFMA0, FULL):
+        _scan(scanner, bank_x2y2, 0.8, 1024, mode)
         assert np.array_equal(scanner.counts(), res4[0]) and scanner.matches()[1].tobytes() == res4[2].tobytes()
+    assert len(scanner.launches()) >= 2  # every column multiplied: the bank does not fit one launch's LDS (bank chunks)
+    scanner.set_column_drop(True)
+    scanner.set_bank(bank_x2y2)
     scanner.process_hits(0.95, 5)
     lines4 = scanner.lines_flat().copy()
     # 64 pages, MFMA == direct; pages 0..3 of the batch are the four above
     big = np.concatenate([pages, synth_pages(bank_x2y2, 60, r_w, r_h, first=3004)])
     scanner.set_pages(big)
     res = {}
-    for mode in (MFMA2, MFMA1, SCAN_DIRECT):
+    for mode in (MFMA1, SCAN_DIRECT):
         scanner.scan(0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
-    res[SCAN_MFMA] = res[MFMA2]
-    assert np.array_equal(res[MFMA1][0], res[SCAN_DIRECT][0]) and res[MFMA1][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
+    res[SCAN_MFMA] = res[MFMA1]
     assert np.array_equal(res[SCAN_MFMA][0], res[SCAN_DIRECT][0])
     assert res[SCAN_MFMA][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
     assert np.array_equal(res[SCAN_MFMA][0][:4], res4[0])
@@ -289,13 +332,13 @@ def test_c5_256_template_gemm_variant(scanner, bank_x2):
     scanner.set_bank(bank)
     scanner.set_pages(pages)
     res = {}
-    for mode in (MFMA1, MFMA2, SCAN_DIRECT):
-        scanner.scan(0.8, 1024, mode)
+    for mode in (MFMA1, SCAN_DIRECT, FULL):
+        _scan(scanner, bank, 0.8, 1024, mode)
         res[mode] = (scanner.counts().copy(),) + scanner.matches()
         names = [li["name"] for li in scanner.launches()]
         assert any(n.startswith("scan_mfma") for n in names) == (mode != SCAN_DIRECT), names
-    res[SCAN_MFMA] = res[MFMA2]
-    for mode in (MFMA1, MFMA2):
+    res[SCAN_MFMA] = res[MFMA1]
+    for mode in (MFMA1, FULL):
         assert np.array_equal(res[mode][0], res[SCAN_DIRECT][0])
         assert res[mode][2].tobytes() == res[SCAN_DIRECT][2].tobytes()
     _assert_equal_ref_batch(res[SCAN_MFMA], pages, bank, 0.8, 1024)
@@ -326,7 +369,7 @@ def _random_bank(rng, shapes, per_shape):
     return Bank(np.concatenate(tm), np.concatenate(needles), len(tm), 0, 0, 13.0, 8.0)
 
 
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", [*MODES, pytest.param(MFMA0, id="legacy"), pytest.param(FULL, id="full")])
 @pytest.mark.parametrize("shapes", [
     [(16, 16), (13, 7), (14, 20)],            # 16-byte-row layout, 4 / 2 / 5 K-steps
     [(8, 15), (5, 9), (3, 3), (1, 1), (8, 32)],  # 8-byte rows only (no 9..12-wide class present)
@@ -335,9 +378,12 @@ def _random_bank(rng, shapes, per_shape):
     [(9, 33), (16, 48), (5, 40), (13, 64), (9, 15)],  # n_h > 32: scan_tall_kernel (plus one MFMA class)
     [(7, 58), (16, 70)],                       # only tall classes; 70 > page height: never searchable
     [(17, 5), (24, 20), (32, 33), (20, 40), (9, 15)],  # 17..32 px wide (extension; the oracle generalises to N = 32)
-], ids=["w16", "w8", "w12", "tall", "taller", "tallest", "wide"])
+    [(13, 15), (12, 15), (9, 14), (8, 14), (9, 30), (13, 32)],  # column drop: 13 -> 12 and 9 -> 8 beside their kept boxes, and alone
+], ids=["w16", "w8", "w12", "tall", "taller", "tallest", "wide", "drop"])
 def test_random_banks_all_layouts(scanner, mode, shapes):
-    rng = np.random.default_rng(hash(str(shapes)) % 2**32)
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(str(shapes).encode()))
     bank = _random_bank(rng, shapes, 7)
     pages = rng.integers(0, 256, (2, 61, 97), dtype=np.uint8)
     # plant a few templates so that high-similarity hits exist too
@@ -347,8 +393,8 @@ def test_random_banks_all_layouts(scanner, mode, shapes):
         pages[0, y:y + nd.shape[0], x:x + nd.shape[1]] = 255 - nd[: 61 - y, : 97 - x]
     scanner.set_bank(bank)
     scanner.set_pages(pages)
-    for thr in (0.25, 0.9):
-        scanner.scan(thr, 1024, mode)
+    for thr in (0.25, 0.9, -0.3):
+        _scan(scanner, bank, thr, 1024, mode)
         offsets, m = scanner.matches()
         _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), _oracle_lists(pages, bank, thr, 1024), f"{shapes} thr={thr}")
 
@@ -364,6 +410,32 @@ def test_c3_bank_16_shifts(scanner, bank_x2y2, mode):
     want = _oracle_lists(pages, bank_x2y2, 0.8, 1024)
     _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2y2)), want, "c3 bank")
     assert sum(len(x) for p in want for x in p) > 1000
+
+
+def test_negative_threshold_exact_bank_noise_pages(scanner):
+    """VERDICT r02 weak #1 on the device: a bank whose int8 quantisation is exact (two-level templates, e_max = 0) on
+    uniform-noise pages at negative thresholds — millions of windows a hair above the threshold, nothing but the
+    threshold arithmetic's own margins between them and the filter.  Every MFMA form against the reference kernel, with a
+    cap large enough that no list is cut (src/ncc.cpp:362-366 decides each window)."""
+    from test_prefilter_host import _bank_of, _two_level
+
+    bank = _bank_of([_two_level(8, 15), _two_level(9, 15, seed=3), _two_level(8, 15, lo=7, hi=250, seed=5)])
+    pages = np.random.default_rng(77).integers(0, 256, (24, 720, 608), dtype=np.uint8)
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    cap = 450_000  # > windows per page: nothing is capped
+    for thr in (-0.25, -0.3):
+        total, wc, wm = O.scan_pages_mt(O.invert(pages), bank, thr, cap, use_ref=O.have_ref(), threads=_host_threads(), keep_matches=True)
+        assert wc.max() < cap and int(total) > 20_000_000
+        flat = wm[np.arange(cap)[None, None, :] < wc[:, :, None]]
+        for mode in (MFMA1, MFMA0, FULL):
+            _scan(scanner, bank, thr, cap, mode)
+            counts = scanner.counts()
+            assert np.array_equal(counts, wc), (thr, mode, int(counts.astype(np.int64).sum() - wc.astype(np.int64).sum()))
+            assert scanner.matches()[1].tobytes() == flat.tobytes(), (thr, mode)
+        scanner.set_column_drop(True)
+        scanner.set_bank(bank)
+    scanner.set_pages(np.full((1, 20, 20), 255, np.uint8))  # give the memory back
 
 
 def test_wide_template_is_rejected(scanner):
@@ -448,15 +520,15 @@ def test_fuzz_geometry_banks_thresholds(scanner):
     """Seeded fuzz over page geometry, bank shapes (all K layouts, class mixes), thresholds and caps; both device
     paths against the oracle, plus process_hits against the oracle's on the same lists."""
     rng = np.random.default_rng(20261004)
-    total_matches = total_chars = capped = two_stage = 0
+    total_matches = total_chars = capped = dropped = 0
     for it in range(150):
         n_classes = int(rng.integers(1, 4))
         shapes = [(int(rng.integers(1, 17)), int(rng.integers(1, 33))) for _ in range(n_classes)]
         if it % 4 == 0:
             shapes = [(int(rng.integers(8, 13)), int(rng.choice([14, 15, 16]))) for _ in range(n_classes)]  # font-like
         per_shape = int(rng.integers(1, 24))
-        if it % 5 == 1:  # banks with enough templates per K layout for the two-stage prefilter to engage
-            shapes = [(int(rng.integers(9, 13)), int(rng.choice([13, 15, 16]))) for _ in range(n_classes)]
+        if it % 5 == 1:  # larger banks; widths 8, 9, 12, 13: classes whose last column is bounded, alone and beside their kept box
+            shapes = [(int(rng.choice([8, 9, 9, 12, 13, 13])), int(rng.choice([13, 15, 16]))) for _ in range(n_classes)]
             per_shape = int(rng.integers(40, 90))
         bank = _random_bank(rng, shapes, per_shape)
         n_pages = int(rng.integers(1, 5))
@@ -472,14 +544,15 @@ def test_fuzz_geometry_banks_thresholds(scanner):
             pages[p, y:y + h, x:x + w] = 255 - nd[:h, :w]
         thr = float(rng.choice([-0.5, 0.1, 0.4, 0.8, 0.97]))
         cap = int(rng.choice([1, 2, 37, 1024]))
+        scanner.set_column_drop(True)
         scanner.set_bank(bank)
         scanner.set_pages(pages)
         want = _oracle_lists(pages, bank, thr, cap)
-        for mode in (MFMA0, MFMA1, MFMA2, SCAN_DIRECT):
-            scanner.scan(thr, cap, mode)
+        dropped += any(w in (9, 13) for w, _ in shapes)
+        for mode in (MFMA0, MFMA1, SCAN_DIRECT, FULL):
+            _scan(scanner, bank, thr, cap, mode)
             offsets, m = scanner.matches()
             _assert_same(_csr_to_lists(offsets, m, n_pages, len(bank)), want, f"fuzz {it} shapes={shapes} {r_w}x{r_h} thr={thr} cap={cap} mode={mode}")
-            two_stage += any(li["name"].startswith("scan_mfma3") for li in scanner.launches())
             total_matches += len(m)
             capped += int((scanner.counts() == cap).sum())
         scanner.process_hits(0.6, 3)
@@ -496,7 +569,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
                 assert lg["similarity"].tobytes() == lw["similarity"].tobytes()
                 total_chars += len(lg)
     assert total_matches > 40000 and total_chars > 500 and capped > 200, (total_matches, total_chars, capped)
-    assert two_stage >= 10, two_stage  # banks large enough for the two-stage prefilter did occur
+    assert dropped >= 30, dropped  # banks with 9- / 13-wide classes (column drop) did occur
 
 
 @pytest.mark.parametrize("mode", MODES)
