@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--prefilter", choices=["auto", "one", "legacy"], default="auto",
                     help="MFMA prefilter kernel (focr_ctx_set_prefilter): auto = one = threshold planes + scan_mfma2s_kernel; "
                          "legacy = round 1's kernel and int32 threshold tables")
+    ap.add_argument("--legacy-tail", action="store_true",
+                    help="round 2's tail (library radix sort of all candidates + verify + compaction) instead of the per-row sort + verify (focr_ctx_set_row_tail(0)), for A/B")
     ap.add_argument("--no-column-drop", action="store_true",
                     help="multiply every template column in the MFMA (focr_ctx_set_column_drop(0)): round 2's 3-K-step form of the 9-wide classes, for A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,9 +148,11 @@ def main():
     from font_ocr_amd.searcher import Pipeline
 
     pipe = Pipeline(local_rank, n_ctx)
-    if args.no_column_drop:
-        for c_ in pipe.scanners:
+    for c_ in pipe.scanners:
+        if args.no_column_drop:
             c_.set_column_drop(False)
+        if args.legacy_tail:
+            c_.set_row_tail(False)
     pipe.set_bank(bank)
     scs, pages = [], None
     shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM
@@ -431,6 +435,7 @@ def main():
             "scan_mode": args.mode,
             "prefilter": args.prefilter,
             "column_drop": not args.no_column_drop,
+            "tail": "legacy radix sort" if args.legacy_tail else "rows",
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
         },
     }

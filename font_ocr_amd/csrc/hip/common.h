@@ -73,6 +73,20 @@ struct KeyFmt {
     __host__ __device__ uint64_t line(uint64_t k) const { return k >> (bt + bx); }  // (page << by) | y
 };
 
+// Per-(page, row) candidate counts for the row path of the tail (rows.hip): every candidate a wave flushes also counts
+// towards its page row (one no-return atomic per candidate; a flush's 64 keys come from a dozen rows).  cnt == nullptr: off.
+struct RowHist {
+    uint32_t *cnt;       // [sub_np * r_h], zeroed at the start of the scan
+    uint32_t r_h;
+    uint32_t shift;      // bt + bx: key >> shift = (page << by) | y   (at most 32 bits)
+    uint32_t by;
+    uint32_t page_base;  // first page of the sub-batch (keys carry absolute page numbers)
+};
+__host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
+    const uint32_t line = (uint32_t)(key >> h.shift);
+    return ((line >> h.by) - h.page_base) * h.r_h + (line & ((1u << h.by) - 1u));
+}
+
 }  // namespace focr
 
 // Item queues of the persistent scan kernels (scan_mfma2.hip): one per launch, QUEUE_XCDS counters QUEUE_STRIDE dwords
@@ -179,6 +193,12 @@ struct focr_ctx {
         void release();
     };
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
+    // row path of the tail (rows.hip): candidates bucketed by page row, sorted + verified per row
+    focr::RowHist row_hist{};   // what the scan kernels' flush path counts into (cnt == nullptr: legacy tail)
+    DevBuf rows_cnt, rows_base, rows_fill, rows_hits, rows_hbase;
+    uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
+    uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
+    bool rows_enabled = true;   // focr_ctx_set_tail(): false = always the legacy tail (radix sort + verify + compaction)
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch
     DevBuf post_line_be;

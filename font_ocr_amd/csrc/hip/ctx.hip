@@ -102,7 +102,7 @@ static void free_results(focr_ctx *c) {
     c->scan_live.release();
     c->scan_live_list.release();
     for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep, &c->acc_matches, &c->acc_seg_count,
-                    &c->acc_hkeys, &c->acc_hsims})
+                    &c->acc_hkeys, &c->acc_hsims, &c->rows_cnt, &c->rows_base, &c->rows_fill, &c->rows_hits, &c->rows_hbase})
         b->release();
     free_dev(c->d_L);
     free_dev(c->d_planes);
@@ -269,6 +269,14 @@ int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
     if (!c || (mode != FOCR_PREFILTER_AUTO && mode != FOCR_PREFILTER_ONE_STAGE && mode != FOCR_PREFILTER_LEGACY))
         return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_prefilter: bad arguments");
     c->prefilter = mode;
+    return FOCR_OK;
+}
+
+int focr_ctx_set_row_tail(focr_ctx_t *c, int on) {
+    if (!c) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: null context");
+    c->rows_enabled = on != 0;
+    c->est_row_max = 0;
+    c->est_cand = c->est_hits = 0;  // the next scan runs with exact sizes
     return FOCR_OK;
 }
 
@@ -647,7 +655,7 @@ int finish_results(focr_ctx *c) {
     if (c->sizes_pending) {
         c->sizes_pending = false;
         const uint64_t n_cand = c->h_res[0], n_hits = c->h_res[1], total = c->h_res[2];
-        if (c->estimated && (c->h_res[4] & 1)) {
+        if (c->estimated && (c->h_res[4] & 3)) {  // bit 0: a count above its bound, bit 1: a page row above the row kernel's capacity
             // a count exceeded the bound taken from the previous scan: redo this batch with exact sizes (and its
             // process_hits, if that was queued behind it)
             const bool redo_post = c->post_pending;
@@ -656,6 +664,7 @@ int finish_results(focr_ctx *c) {
             c->est_cand = c->est_hits = 0;
             c->est_var = 0.0667;  // back to the 20 % margin
             c->est_last_cand = c->est_last_hits = 0;
+            c->est_row_max = 0;
             c->counters_redone++;
             int rc = scan_now(c);
             if (rc) return rc;
@@ -688,6 +697,7 @@ int finish_results(focr_ctx *c) {
             const double margin = std::min(0.2, std::max(0.04, 3.0 * c->est_var));
             c->est_cand = (size_t)n_cand + (size_t)((double)n_cand * margin) + 8192;
             c->est_hits = (size_t)n_hits + (size_t)((double)n_hits * margin) + 8192;
+            c->est_row_max = c->row_cap ? (uint32_t)std::max<uint64_t>(c->h_res[5], 1) : 0;  // 0: the last scan took the legacy tail
         }
         c->counters[1] = n_hits;
         c->n_hits = c->n_hits_raw = (size_t)n_hits;
@@ -742,6 +752,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
                        (uint64_t)c->prefilter})
         sig = (sig ^ v) * 1099511628211ull;
     if (sig != c->est_sig) {
+        c->est_row_max = 0;
         c->est_cand = c->est_hits = 0;
         c->est_var = 0.0667;
         c->est_last_cand = c->est_last_hits = 0;

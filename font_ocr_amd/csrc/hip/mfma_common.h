@@ -12,12 +12,24 @@ constexpr uint32_t WBUF = 64;           // wave-private candidate staging entrie
 
 // one global atomic per flush: lane 0 reserves `count` slots, the wave copies its staged keys out coalesced
 __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t count, int lane, uint64_t *__restrict__ cand,
-                                                      unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap) {
+                                                      unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, const RowHist &rows) {
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(cand_counter, (unsigned long long)count);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)hi << 32) | lo;
-    if ((uint32_t)lane < count && base + lane < cand_cap) cand[base + lane] = wbuf[lane];
+    const bool valid = (uint32_t)lane < count;
+    const uint64_t key = valid ? wbuf[lane] : 0;
+    if (valid && base + lane < cand_cap) cand[base + lane] = key;
+    if (rows.cnt) {  // row counts (rows.hip): one atomic per distinct row among the flushed keys, not one per key
+        const uint32_t r = valid ? row_of_key(key, rows) : 0xffffffffu;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
+            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
+            if (lane == (int)__builtin_ctzll(peers)) atomicAdd(rows.cnt + r0, (uint32_t)__builtin_popcountll(peers));
+            todo &= ~peers;
+        }
+    }
 }
 
 // ---- threshold planes ------------------------------------------------------------------------
@@ -238,6 +250,53 @@ struct MfmaLaunch {
     uint32_t Lpitch, Lrows;
     uint64_t alg_macs;    // algorithmic MACs of the chunk (true template area x searched windows x templates x pages)
 };
+
+// ---- exact verify of one candidate: the reference arithmetic, operation for operation (common.h) ----
+typedef v4i v4i_b1 __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
+struct VerifyArgs {
+    const uint8_t *pages;
+    uint32_t pitch, rows_alloc;
+    KeyFmt fmt;
+    const uint32_t *order_of;        // global template index -> class-ordered index
+    const TemplateConst *tc;         // class-ordered
+    const v4i *needles16;            // every template as n_h rows of 16 bytes (zero padded; two halves per row above 16 px)
+    const uint32_t *needle16_row;    // class-ordered first row
+    double thr_d;
+};
+VerifyArgs verify_args(const focr_ctx *c, double thr_d);  // scan_mfma.hip
+__device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs &va, float *sim_out) {
+    const uint32_t page = va.fmt.page(key), t = va.fmt.t(key), x = va.fmt.x(key), y = va.fmt.y(key);
+    const uint32_t ci = va.order_of[t];
+    const TemplateConst c = va.tc[ci];
+    // template rows: 16 bytes each, zero padded past n_w (two 16-byte halves per row for the 17..32-wide extension)
+    const uint32_t halves = c.n_w > 16 ? 2 : 1;
+    const v4i *nd = va.needles16 + va.needle16_row[ci];
+    const uint8_t *pg = va.pages + ((size_t)page * va.rows_alloc + y) * va.pitch + x;  // rows have >= 64 readable bytes past r_w
+    uint32_t acc = 0, s_p = 0, s2_p = 0;
+    for (uint32_t hf = 0; hf < halves; hf++) {
+        // byte mask of the window's own columns (the padded template columns are zero, but s_p / s2_p need the mask)
+        const uint32_t w_here = min(c.n_w - 16 * hf, 16u);
+        v4i keep;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            keep[k] = w_here >= (uint32_t)(4 * k + 4) ? -1 : (w_here <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (w_here - 4 * k))) - 1u));
+#pragma unroll 8
+        for (uint32_t j = 0; j < c.n_h; j++) {
+            const v4i a = *reinterpret_cast<const v4i_b1 *>(pg + (size_t)j * va.pitch + 16 * hf) & keep;
+            const v4i b = nd[j * halves + hf];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
+                s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
+                s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
+            }
+        }
+    }
+    const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
+    const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
+    *sim_out = (float)sim;
+    return ncc_emits(sim, va.thr_d);
+}
 
 // Per-launch description of the threshold planes of the pass's size classes (scan_mfma2s_kernel).
 constexpr int MAX_PLANE_VALUES = 4;  // size classes per pass on the plane path (the kernel is instantiated for 1 / 2 / 4)

@@ -1,0 +1,329 @@
+// rows.hip — the row path of the scan's tail: candidates -> sorted, verified hits, without a global sort.
+//
+// The prefilter leaves an unordered list of candidate keys (page, y, x, t).  The reference's order (process_hits order:
+// page, y, x, template; src/ncc.rs:741-752) used to be restored by a 5-pass radix sort of all candidates, followed by the
+// exact verify, a flag scan and a compaction (12 launches, ~0.5 ms alone on the chip at BASELINE configs[1]).  But a
+// candidate's (page, y) is one of only sub_np * r_h page rows (92 160 at configs[1], ~50 candidates each), so:
+//
+//   scan kernels      every flushed candidate also counts towards its page row            (flush_wave_candidates, RowHist)
+//   row_prefix        exclusive prefix of the row counts -> row_base, the largest row        1 workgroup
+//   row_scatter       candidate -> row_base[row] + (next free slot of the row)               order inside a row: arbitrary
+//   row_sort<CAP>     one WAVE per row, wave-private LDS: counting sort by x, rank inside the x-bin by t — in place
+//   verify_flat       the reference arithmetic on every candidate (verify_candidate, mfma_common.h), one thread each: the
+//                     row-ordered list is dense, neighbouring lanes read the same page lines
+//   row_pack          one wave per row: the survivors to the front of the row's slots, order kept; the row's hit count
+//   row_prefix        exclusive prefix of the rows' hit counts -> the dense position of every row's hits, the hit total
+//   row_compact       rows -> dense (key, similarity) arrays in (page, y, x, t) order      what order.hip takes over
+//
+// Eight small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A row with more candidates than the
+// instantiated capacity (the host picks 256 / 1024 / 4096 from the largest row: exact mode knows it, estimated mode takes the
+// previous scan's) sets the overflow bit and the batch is redone; rows beyond 4096 candidates (very low thresholds) and
+// banks with tall classes take the legacy tail (scan_mfma.hip: radix sort + verify_kernel + compaction).
+#include "mfma_common.h"
+
+namespace focr {
+
+int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c);
+int ensure_hit_capacity(focr_ctx *c, size_t want);
+
+// exclusive prefix of n u32 counts by ONE workgroup: base[0..n] (base[n] = total); *total_out = total, *max_out = max
+// (u64 each; either may be null); zero[0..n) is cleared on the way if given (the scatter's per-row cursors).  Each of the 16
+// waves owns a contiguous segment and walks it 64 entries at a time (coalesced), twice: sums first, then the prefix.
+__global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ base,
+                                                          uint32_t *__restrict__ zero, uint64_t *__restrict__ total_out,
+                                                          uint64_t *__restrict__ max_out) {
+    __shared__ uint32_t wave_sum[16], wave_max[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t seg = ((n + 15) / 16 + 63) / 64 * 64, b = min(n, wv * seg), e = min(n, b + seg);
+    uint32_t sum = 0, mx = 0;
+#pragma unroll 4
+    for (uint32_t i = b + lane; i < e; i += 64) {
+        const uint32_t v = cnt[i];
+        sum += v;
+        mx = max(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += (uint32_t)__shfl_xor((int)sum, o);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    if (lane == 0) {
+        wave_sum[wv] = sum;
+        wave_max[wv] = mx;
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t q = 0; q < wv; q++) carry += wave_sum[q];
+    for (uint32_t i0 = b; i0 < e; i0 += 64) {
+        const uint32_t i = i0 + lane, v = i < e ? cnt[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += u;
+        }
+        if (i < e) {
+            base[i] = carry + incl - v;
+            if (zero) zero[i] = 0;
+        }
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, m = 0;
+        for (int q = 0; q < 16; q++) {
+            tot += wave_sum[q];
+            m = max(m, wave_max[q]);
+        }
+        base[n] = tot;
+        if (total_out) *total_out = tot;
+        if (max_out) *max_out = m;
+    }
+}
+
+// candidate -> its row's slots.  The candidate list is in flush order: the 64 keys of a wave come from a dozen rows, and
+// neighbouring waves fill the same rows, whose cursors share cache lines — so the wave adds once per distinct row (leader
+// lane, count of its peers) instead of once per candidate.
+__global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p,
+                                                          unsigned long long cap, const RowHist rows, const uint32_t *__restrict__ base,
+                                                          uint32_t *__restrict__ fill, uint64_t *__restrict__ bucket) {
+    const unsigned long long n = min(*n_cand_p, cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {  // wave-uniform trip count
+        const unsigned long long i = i0 + lane;
+        const bool valid = i < n;
+        const uint64_t key = valid ? cand[i] : 0;
+        const uint32_t r = valid ? row_of_key(key, rows) : 0xffffffffu;
+        uint32_t slot = 0;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+        while (todo) {  // one pass per distinct row among the wave's keys
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
+            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
+            uint32_t first = 0;
+            if (lane == (int)__builtin_ctzll(peers)) first = atomicAdd(fill + r0, (uint32_t)__builtin_popcountll(peers));
+            first = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(peers));
+            if (r == r0) slot = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            todo &= ~peers;
+        }
+        if (valid) bucket[(size_t)base[r] + slot] = key;  // slot < cnt[r]: every stored candidate was counted
+    }
+}
+
+// Sort every row's candidates by (x, t) — the low bt + bx bits of the key, unique inside a row — in place.  One WAVE per row
+// (fixed stride: dense text rows are spread evenly over the waves), wave-private LDS, no workgroup barrier:
+//   counting sort by x-bin (bin = x >> xs, at most XBINS bins: one x per bin for pages up to 1024 px wide) — count, exclusive
+//   prefix, place — then every element finds its rank among the few elements of its own bin and goes straight back to the
+//   row's slots in global memory.  O(n) LDS operations per row instead of a bitonic network's O(n log^2 n).
+constexpr uint32_t XBINS = 1024;
+template <int CAP>
+__global__ __launch_bounds__(256) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+                                                       uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t xs,
+                                                       uint32_t n_bins, unsigned long long *__restrict__ flags_word) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 cursors, CAP sub-keys
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *cur = sort_lds + (size_t)wv * (XBINS + 1 + CAP) + 1;  // cur[-1] = 0: the start of bin 0
+    uint32_t *out = cur + XBINS;
+    const uint32_t wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+    const uint64_t sub_mask = (1ull << sub_bits) - 1;
+    for (uint32_t r = wave; r < n_rows; r += n_waves) {
+        const uint32_t n = fill[r];
+        if (n < 2) continue;
+        if (n > (uint32_t)CAP) {  // the host sized the kernel from an estimate that did not hold: the batch is redone
+            if (lane == 0) atomicOr(flags_word, 2ull);
+            continue;
+        }
+        uint64_t *row = bucket + base[r];
+        for (uint32_t i = lane; i <= n_bins; i += 64) cur[(int)i - 1] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t j = lane; j < n; j += 64) atomicAdd(&cur[(uint32_t)((row[j] & sub_mask) >> bt) >> xs], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t carry = 0;  // exclusive prefix over the bins, 64 at a time
+        for (uint32_t i0 = 0; i0 < n_bins; i0 += 64) {
+            const uint32_t i = i0 + lane, v = i < n_bins ? cur[i] : 0;
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            if (i < n_bins) cur[i] = carry + incl - v;
+            carry += __shfl(incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t high = row[0] & ~sub_mask;  // (page, y): the same for the whole row
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t sub = (uint32_t)(row[j] & sub_mask);
+            out[atomicAdd(&cur[(sub >> bt) >> xs], 1u)] = sub;  // cur[bin] ends up at the end of its bin
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t e = out[j], bin = (e >> bt) >> xs, lo = cur[(int)bin - 1], hi = cur[bin];
+            uint32_t rank = 0;
+            for (uint32_t i = lo; i < hi; i++) rank += out[i] < e;
+            row[lo + rank] = high | e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next row reuses the LDS buffers
+    }
+}
+
+// exact verify, one thread per candidate of the row-ordered list (perfectly balanced); similarity + emit flag in place
+__global__ __launch_bounds__(256) void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
+                                                          const VerifyArgs va, float *__restrict__ bsims, uint8_t *__restrict__ bflags) {
+    const unsigned long long n = min((unsigned long long)*total_p, cap);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        float sim;
+        const bool emit = verify_candidate(bucket[i], va, &sim);
+        bsims[i] = sim;
+        bflags[i] = emit ? 1 : 0;
+    }
+}
+
+// survivors of a row to the front of its slots (order kept), one wave per row; row_hits[r] = their number
+__global__ __launch_bounds__(256) void row_pack_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+                                                       uint64_t *__restrict__ bucket, float *__restrict__ bsims, const uint8_t *__restrict__ bflags,
+                                                       uint32_t *__restrict__ row_hits) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (uint32_t r = wave; r < n_rows; r += n_waves) {
+        const uint32_t n = fill[r];
+        const size_t b = base[r];
+        uint32_t nh = 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool valid = j < n;
+            const uint64_t key = valid ? bucket[b + j] : 0;
+            const float sim = valid ? bsims[b + j] : 0.f;
+            const bool emit = valid && bflags[b + j];
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
+            if (emit) {  // position <= b + j: only slots this wave has already read are overwritten
+                const uint32_t pos = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                bucket[b + pos] = key;
+                bsims[b + pos] = sim;
+            }
+            nh += (uint32_t)__builtin_popcountll(mask);
+        }
+        if (lane == 0) row_hits[r] = nh;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ row_hits,
+                                                          const uint32_t *__restrict__ hbase, const uint64_t *__restrict__ bucket,
+                                                          const float *__restrict__ bsims, uint64_t *__restrict__ hkeys, float *__restrict__ hsims,
+                                                          unsigned long long hit_cap) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (uint32_t r = wave; r < n_rows; r += n_waves) {
+        const uint32_t n = row_hits[r];
+        const size_t src = base[r], dst = hbase[r];
+        for (uint32_t j = lane; j < n; j += 64)
+            if (dst + j < hit_cap) {  // estimated sizes: a hit count above its bound is flagged by record_scan_sizes and redone
+                hkeys[dst + j] = bucket[src + j];
+                hsims[dst + j] = bsims[src + j];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+bool rows_applicable(const focr_ctx *c) {
+    if (!c->rows_enabled) return false;
+    for (const SizeClass &sc : c->classes)
+        if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per row
+    return c->sub_np * c->r_h <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32;
+}
+
+// before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
+int rows_begin(focr_ctx *c) {
+    const size_t n_rows = c->sub_np * c->r_h;
+    uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, (n_rows + 1) * 4);
+    if (!cnt || !c->rows_base.ensure(c, (n_rows + 1) * 4) || !c->rows_fill.ensure(c, (n_rows + 1) * 4) || !c->rows_hits.ensure(c, (n_rows + 1) * 4) ||
+        !c->rows_hbase.ensure(c, (n_rows + 1) * 4))
+        return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    FOCR_HIP(c, hipMemsetAsync(cnt, 0, n_rows * 4, c->stream));
+    c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0};
+    return FOCR_OK;
+}
+
+// right after the scan kernels: row_base, cursors cleared, the largest row -> d_res[5]
+int rows_prefix(focr_ctx *c) {
+    const uint32_t n_rows = (uint32_t)(c->sub_np * c->r_h);
+    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->rows_cnt.p, n_rows, (uint32_t *)c->rows_base.p,
+                       (uint32_t *)c->rows_fill.p, (uint64_t *)nullptr, c->d_res + 5);
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 256 ? 256u : row_max <= 1024 ? 1024u : row_max <= 4096 ? 4096u : 0u; }
+
+// scatter, per-row sort + verify, compaction: leaves the dense sorted hits in d_hit_keys / d_hit_sims_alt and their number in
+// d_res[6]; records ev[3] behind the verify
+int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class) {
+    const uint32_t n_rows = (uint32_t)(c->sub_np * c->r_h);
+    int rc;
+    if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
+    if (c->cand_alt_capacity < c->cand_capacity) {
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_cand_alt) (void)hipFree(c->d_cand_alt);
+        c->d_cand_alt = nullptr;
+        c->cand_alt_capacity = 0;
+        if (hipMalloc(&c->d_cand_alt, c->cand_capacity * 8) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+        c->cand_alt_capacity = c->cand_capacity;
+    }
+    float *bsims = (float *)c->scan_pos.ensure(c, (ub_c + 1) * 4);
+    if (!bsims) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    hipDeviceProp_t prop;
+    FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    const unsigned cus = (unsigned)prop.multiProcessorCount;
+    const uint32_t *base = (const uint32_t *)c->rows_base.p;
+    uint32_t *fill = (uint32_t *)c->rows_fill.p, *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
+    if (ub_c) {
+        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16);
+        hipLaunchKernelGGL(row_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, c->d_cand, n_cand_p, (unsigned long long)ub_c, c->row_hist, base, fill,
+                           c->d_cand_alt);
+        FOCR_HIP(c, hipGetLastError());
+    }
+    const VerifyArgs va = verify_args(c, thr_d);
+    unsigned long long *flags_word = (unsigned long long *)(c->d_res + 4);
+    uint8_t *bflags = (uint8_t *)c->scan_flags.ensure(c, ub_c + 16);
+    if (!bflags) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
+    {
+        const uint32_t cap = cap_class <= 256 ? 256 : cap_class <= 1024 ? 1024 : 4096;
+        const size_t lds = (size_t)4 * (XBINS + 1 + cap) * 4;
+        uint32_t xs = 0;
+        while (((uint32_t)c->r_w >> xs) + 1 > XBINS) xs++;
+        const uint32_t n_bins = ((uint32_t)c->r_w >> xs) + 1;
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(row_blocks), dim3(256), lds, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx,
+                               c->fmt.bt, xs, n_bins, flags_word);
+        };
+        if (cap == 256) launch(row_sort_kernel<256>);
+        else if (cap == 1024) launch(row_sort_kernel<1024>);
+        else launch(row_sort_kernel<4096>);
+        FOCR_HIP(c, hipGetLastError());
+    }
+    if (ub_c) {
+        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 64);
+        hipLaunchKernelGGL(verify_flat_kernel, dim3(nb), dim3(256), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va, bsims,
+                           bflags);
+        FOCR_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(row_pack_kernel, dim3(row_blocks), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, bsims, (const uint8_t *)bflags,
+                       hits);
+    FOCR_HIP(c, hipGetLastError());
+    FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6,
+                       (uint64_t *)nullptr);
+    FOCR_HIP(c, hipGetLastError());
+    {
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
+        hipLaunchKernelGGL(row_compact_kernel, dim3(nb), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)hits, (const uint32_t *)hbase,
+                           (const uint64_t *)c->d_cand_alt, (const float *)bsims, c->d_hit_keys, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+        FOCR_HIP(c, hipGetLastError());
+    }
+    return FOCR_OK;
+}
+
+}  // namespace focr

@@ -46,6 +46,12 @@ int launch_scan_tall(focr_ctx *c, size_t k, double thr_d, uint64_t *keys, float 
 int compact_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, const uint64_t *flags, uint64_t *pos,
                        const unsigned long long *n_cand_p, size_t ub_c);
 int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c);
+// rows.hip: the row path of the tail
+bool rows_applicable(const focr_ctx *c);
+int rows_begin(focr_ctx *c);
+int rows_prefix(focr_ctx *c);
+uint32_t rows_capacity_for(uint64_t row_max);
+int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class);
 
 
 // ---------------------------------------------------------------------------------------------
@@ -243,56 +249,23 @@ __global__ __launch_bounds__(256) void compact_live_tiles(const uint8_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. exact verify: the reference arithmetic on every candidate
-typedef v4i v4i_u __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
-
-// Candidates arrive sorted by the packed key (page, y, x, t): neighbouring lanes verify the same or neighbouring
-// windows (cache-friendly), and the survivors stay in process_hits order, so no atomics: flag[i] / sim[i] are
-// written in place and order.hip compacts them and derives the per-call lists.
+// 3. exact verify: the reference arithmetic on every candidate (verify_candidate, mfma_common.h)
+//
+// Legacy tail (fallback of the row path, rows.hip): candidates arrive radix-sorted by the packed key (page, y, x, t):
+// neighbouring lanes verify the same or neighbouring windows (cache-friendly), and the survivors stay in process_hits order,
+// so no atomics: flag[i] / sim[i] are written in place and order.hip compacts them and derives the per-call lists.
 __global__ __launch_bounds__(256) void verify_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long ub,
-                                                     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
-                                                     KeyFmt fmt, const uint32_t *__restrict__ order_of,
-                                                     const TemplateConst *__restrict__ tc, const v4i *__restrict__ needles16,
-                                                     const uint32_t *__restrict__ needle16_row, double thr_d,
-                                                     float *__restrict__ sims, uint64_t *__restrict__ flags) {
+                                                     const VerifyArgs va, float *__restrict__ sims, uint64_t *__restrict__ flags) {
     unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > ub) return;  // grid and buffers are sized for `ub` candidates (+ the sentinel at ub)
     if (i >= min(*n_cand_p, ub)) {  // past the device-side count (and the sentinel: the exclusive scan of flags also yields the total)
         flags[i] = 0;
         return;
     }
-    const uint64_t key = cand[i];
-    const uint32_t page = fmt.page(key), t = fmt.t(key), x = fmt.x(key), y = fmt.y(key);
-    const uint32_t ci = order_of[t];
-    const TemplateConst c = tc[ci];
-    // template rows: 16 bytes each, zero padded past n_w (two 16-byte halves per row for the 17..32-wide extension)
-    const uint32_t halves = c.n_w > 16 ? 2 : 1;
-    const v4i *nd = needles16 + needle16_row[ci];
-    const uint8_t *pg = pages + ((size_t)page * rows_alloc + y) * pitch + x;  // rows have >= 64 readable bytes past r_w
-    uint32_t acc = 0, s_p = 0, s2_p = 0;
-    for (uint32_t hf = 0; hf < halves; hf++) {
-        // byte mask of the window's own columns (the padded template columns are zero, but s_p / s2_p need the mask)
-        const uint32_t w_here = min(c.n_w - 16 * hf, 16u);
-        v4i keep;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            keep[k] = w_here >= (uint32_t)(4 * k + 4) ? -1 : (w_here <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (w_here - 4 * k))) - 1u));
-#pragma unroll 8
-        for (uint32_t j = 0; j < c.n_h; j++) {
-            const v4i a = *reinterpret_cast<const v4i_u *>(pg + (size_t)j * pitch + 16 * hf) & keep;
-            const v4i b = nd[j * halves + hf];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
-                s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
-                s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
-            }
-        }
-    }
-    const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
-    const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
-    sims[i] = (float)sim;
-    flags[i] = ncc_emits(sim, thr_d) ? 1 : 0;
+    float sim;
+    const bool emit = verify_candidate(cand[i], va, &sim);
+    sims[i] = sim;
+    flags[i] = emit ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +510,11 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
     return FOCR_OK;
 }
 
+VerifyArgs verify_args(const focr_ctx *c, double thr_d) {
+    return VerifyArgs{c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of, c->d_tconst,
+                      reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d};
+}
+
 // Process-wide hand-over of the scan kernel between contexts of one device (events are never destroyed).
 struct ScanTurns {
     std::mutex mu;
@@ -588,7 +566,18 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         // previous scan): the counts stay on the device, grids and buffers take the previous counts + a margin (4 .. 20 %, ctx.hip) as bounds,
         // unused candidate slots hold the largest key so that the sort leaves them at the end; nothing waits.
         c->ub_cand = c->estimated ? std::min(c->est_cand, c->cand_capacity) : c->cand_capacity;
-        if (c->estimated) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
+        // Tail: the row path (rows.hip) unless a row could exceed its capacity — exact mode finds out after the scan kernels,
+        // estimated mode goes by the previous scan's largest row + 25 % (a larger one sets the overflow bit: batch redone).
+        bool use_rows = rows_applicable(c);
+        uint32_t row_cap = 0;
+        if (use_rows && c->estimated) {
+            row_cap = rows_capacity_for((uint64_t)c->est_row_max + c->est_row_max / 4 + 16);
+            use_rows = c->est_row_max != 0 && row_cap != 0;
+        }
+        c->row_hist = RowHist{};
+        if (use_rows && (rc = rows_begin(c))) return rc;
+        // legacy tail, estimated sizes: unused candidate slots hold the largest key so that the radix sort leaves them at the end
+        if (c->estimated && !use_rows) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // `sim > +inf` is never true (NaN thresholds arrive here as +inf, focr_scan): no statistics, no scan, zero candidates
         // (kappa would be inf - inf = NaN and every window of every live tile a candidate for verify to reject)
@@ -771,10 +760,17 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipMemcpyAsync(c->h_live, c->d_counter + 8, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         const unsigned long long *n_cand_p = (const unsigned long long *)c->d_counter + 1;
         size_t ub_c = c->ub_cand;
+        if (use_rows && !nothing && (rc = rows_prefix(c))) return rc;
+        if (nothing) use_rows = false;
         if (!c->estimated) {
-            unsigned long long n_cand = 0;
+            unsigned long long n_cand = 0, row_max = 0;
             FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
+            if (use_rows) FOCR_HIP(c, hipMemcpyAsync(&row_max, c->d_res + 5, 8, hipMemcpyDeviceToHost, c->stream));
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            if (use_rows) {
+                row_cap = rows_capacity_for(row_max);
+                use_rows = row_cap != 0;  // a row beyond the largest capacity: legacy tail for this scan
+            }
             if (n_cand > c->cand_capacity) {
                 if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
                 want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;
@@ -782,7 +778,20 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             }
             ub_c = (size_t)n_cand;
         }
-        // 3. sort the candidates into emission order, verify them exactly in place, compact + cap (order.hip)
+        c->row_cap = use_rows ? row_cap : 0;
+        if (use_rows) {
+            // 3a. row path: bucket by page row, sort + verify per row, compact (rows.hip), then the ordering pass
+            if ((rc = rows_tail(c, thr_d, n_cand_p, ub_c, row_cap))) return rc;
+            size_t ub_h = std::min(ub_c, c->est_hits);
+            if (!c->estimated) {  // exact number of hits for the ordering pass
+                uint64_t hits = 0;
+                FOCR_HIP(c, hipMemcpyAsync(&hits, c->d_res + 6, 8, hipMemcpyDeviceToHost, c->stream));
+                FOCR_HIP(c, hipStreamSynchronize(c->stream));
+                ub_h = (size_t)hits;
+            }
+            return order_sorted_hits(c, c->d_hit_keys, c->d_hit_sims_alt, c->d_res + 6, ub_h, n_cand_p, ub_c);
+        }
+        // 3b. legacy tail: sort the candidates into emission order, verify them exactly in place, compact + cap (order.hip)
         if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
         uint64_t *flags = (uint64_t *)c->scan_flags.ensure(c, (ub_c + 1) * 8);
         uint64_t *pos = (uint64_t *)c->scan_pos.ensure(c, (ub_c + 1) * 8);
@@ -797,9 +806,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         }
         if ((rc = sort_keys_u64(c, c->d_cand, c->d_cand_alt, ub_c, c->fmt.bits()))) return rc;
         hipLaunchKernelGGL(verify_kernel, dim3((unsigned)((ub_c + 1 + 255) / 256)), dim3(256), 0, c->stream, c->d_cand, n_cand_p, (unsigned long long)ub_c,
-                           c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of,
-                           c->d_tconst, reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, c->d_hit_sims,
-                           flags);
+                           verify_args(c, thr_d), c->d_hit_sims, flags);
         FOCR_HIP(c, hipGetLastError());
         FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
         if ((rc = compact_candidates(c, c->d_cand, c->d_hit_sims, flags, pos, n_cand_p, ub_c))) return rc;

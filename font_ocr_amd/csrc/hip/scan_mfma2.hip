@@ -38,7 +38,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue, const RowHist rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
                             if (cnt) {
                                 if (wcount + cnt > WBUF) {
-                                    flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                                    flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
                                     wcount = 0;
                                 }
                                 const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
         }
         }
     }
-    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const PlaneArgs P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
-    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue) {
+    unsigned long long *__restrict__ cand_counter, unsigned long long cand_cap, uint32_t *__restrict__ queue, const RowHist rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     v4i *bank = reinterpret_cast<v4i *>(smem);
     const uint32_t bank_vec = n_tiles16 * KSTEPS * 64;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
                             if (wcount + cnt > WBUF) {
                                 PROF2(3)
-                                flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+                                flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
                                 wcount = 0;
                                 PROF2(4)
 #ifdef FOCR_V2S_PROF
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         }
         PROF2(2)
     }
-    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap);
+    if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
 #ifdef FOCR_V2S_PROF
     if (lane == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&focr_prof2[i], prof_acc[i]);
@@ -443,7 +443,7 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, un
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
-                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue);
+                       c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue, c->row_hist);
     c->launch_end();
 }
 
@@ -494,7 +494,7 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
-                       (unsigned long long)c->ub_cand, L.queue);
+                       (unsigned long long)c->ub_cand, L.queue, c->row_hist);
     c->launch_end();
 }
 

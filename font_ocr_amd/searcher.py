@@ -174,6 +174,11 @@ class Scanner:
         """PREFILTER_AUTO / PREFILTER_ONE_STAGE / PREFILTER_LEGACY (focr_ctx_set_prefilter); results never change."""
         self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
 
+    def set_row_tail(self, on):
+        """focr_ctx_set_row_tail: per-row sort + verify of the candidates (default) or the legacy radix-sort tail; results
+        never change."""
+        self._ck(self._lib.focr_ctx_set_row_tail(self._h, int(bool(on))))
+
     def set_column_drop(self, on):
         """focr_ctx_set_column_drop: bound the last column of 9- / 13-wide classes instead of multiplying it (default on);
         takes effect at the next set_bank; results never change."""

@@ -233,6 +233,12 @@ int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
  * the next focr_bank_upload. */
 int focr_ctx_set_column_drop(focr_ctx_t *ctx, int on);
 
+/* Tail of the MFMA scan (default on = the row path, rows.hip): candidates are bucketed by page row, sorted and verified
+ * per row in LDS.  Off = the legacy tail (library radix sort of all candidates, verify, flag scan, compaction), which
+ * also serves batches the row path does not cover (a page row with more than 4096 candidates, banks with templates
+ * taller than 32 px).  Results are identical either way. */
+int focr_ctx_set_row_tail(focr_ctx_t *ctx, int on);
+
 /* Result sizes.  Every phase behind the scan kernel takes its element count from device memory.  A scan of the same
  * setup as the context's previous one (same bank, batch geometry, threshold, cap) bounds its buffers by the previous
  * scan's counts + a margin (4 .. 20 %, following how much consecutive counts differ), queues all phases (and a following focr_process_hits) without a host wait, and the first call

@@ -31,6 +31,7 @@ def _column_drop_back_on(request):
     yield
     if "scanner" in request.fixturenames:
         request.getfixturevalue("scanner").set_column_drop(True)
+        request.getfixturevalue("scanner").set_row_tail(True)
 
 
 def _scan(scanner, bank, thr, cap, mode):
@@ -242,6 +243,14 @@ def test_full_size_c2_properties(scanner, bank_x2):
         assert res[SCAN_DIRECT][2].tobytes() == res[mode][2].tobytes()
     # the price of the bound: more candidates for verify to reject, the same hits (about 1.2 x)
     assert cand[FULL] < cand[MFMA1] < 1.5 * cand[FULL], cand
+    # the tail: per-row sort + verify (rows.hip, the default: the scans above) against the legacy radix-sort tail
+    scanner.set_row_tail(False)
+    scanner.scan(0.8, 1024, MFMA1)
+    assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes()
+    scanner.set_row_tail(True)
+    scanner.scan(0.8, 1024, MFMA1)  # first scan after the switch: exact sizes
+    scanner.scan(0.8, 1024, MFMA1)  # estimated sizes on the row path
+    assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes()
     res[SCAN_MFMA] = res[FULL]
     scanner.process_hits(0.95, 5)
     lines = scanner.lines()
@@ -299,6 +308,7 @@ def test_c3_geometry_1200x1600_vs_reference(scanner, bank_x2y2):
     assert len(scanner.launches()) >= 2  # every column multiplied: the bank does not fit one launch's LDS (bank chunks)
     scanner.set_column_drop(True)
     scanner.set_bank(bank_x2y2)
+    scanner.scan(0.8, 1024, MFMA1)
     scanner.process_hits(0.95, 5)
     lines4 = scanner.lines_flat().copy()
     # 64 pages, MFMA == direct; pages 0..3 of the batch are the four above
@@ -545,6 +555,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
         thr = float(rng.choice([-0.5, 0.1, 0.4, 0.8, 0.97]))
         cap = int(rng.choice([1, 2, 37, 1024]))
         scanner.set_column_drop(True)
+        scanner.set_row_tail(it % 3 != 2)  # every third case through the legacy tail
         scanner.set_bank(bank)
         scanner.set_pages(pages)
         want = _oracle_lists(pages, bank, thr, cap)

@@ -10,6 +10,7 @@ P = int(os.environ.get("KB_PAGES", "128"))
 pages = synth_pages(bank, P, 608, 720)
 sc = Scanner(0); sc.set_bank(bank); sc.set_pages(pages)
 sc.set_prefilter(int(os.environ.get("KB_PREFILTER", "0")))
+if os.environ.get("KB_LEGACY_TAIL"): sc.set_row_tail(False)
 if os.environ.get("KB_SCAN_CUS"): sc.set_scan_cus(int(os.environ["KB_SCAN_CUS"]))
 for _ in range(2): sc.scan(0.8, 1024, SCAN_MFMA)
 acc = {}
