@@ -195,7 +195,7 @@ struct focr_ctx {
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
     // row path of the tail (rows.hip): candidates bucketed by page row, sorted + verified per row
     focr::RowHist row_hist{};   // what the scan kernels' flush path counts into (cnt == nullptr: legacy tail)
-    DevBuf rows_cnt, rows_base, rows_fill, rows_hits, rows_hbase;
+    DevBuf rows_cnt, rows_base, rows_fill, rows_hits, rows_hbase, rows_big;
     uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
     uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
     bool rows_enabled = true;   // focr_ctx_set_tail(): false = always the legacy tail (radix sort + verify + compaction)

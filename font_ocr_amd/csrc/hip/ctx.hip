@@ -102,7 +102,7 @@ static void free_results(focr_ctx *c) {
     c->scan_live.release();
     c->scan_live_list.release();
     for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep, &c->acc_matches, &c->acc_seg_count,
-                    &c->acc_hkeys, &c->acc_hsims, &c->rows_cnt, &c->rows_base, &c->rows_fill, &c->rows_hits, &c->rows_hbase})
+                    &c->acc_hkeys, &c->acc_hsims, &c->rows_cnt, &c->rows_base, &c->rows_fill, &c->rows_hits, &c->rows_hbase, &c->rows_big})
         b->release();
     free_dev(c->d_L);
     free_dev(c->d_planes);
@@ -655,6 +655,7 @@ int finish_results(focr_ctx *c) {
     if (c->sizes_pending) {
         c->sizes_pending = false;
         const uint64_t n_cand = c->h_res[0], n_hits = c->h_res[1], total = c->h_res[2];
+        if (c->h_res[4] & 4) return fail(c, FOCR_ERR_STATE, "internal error: a candidate key outside the batch reached the verify stage");
         if (c->estimated && (c->h_res[4] & 3)) {  // bit 0: a count above its bound, bit 1: a page row above the row kernel's capacity
             // a count exceeded the bound taken from the previous scan: redo this batch with exact sizes (and its
             // process_hits, if that was queued behind it)
@@ -760,6 +761,15 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     c->est_sig = sig;
     c->estimated = c->estimates_enabled && mode == FOCR_SCAN_MFMA && !c->force_split && c->est_cand != 0;
     return scan_now(c);
+}
+
+int focr_size_estimate_stats(focr_ctx_t *c, uint64_t *redone, double *margin, uint32_t *row_max) {
+    if (!c) return FOCR_ERR_INVALID;
+    if (int rc = finish_results(c)) return rc;
+    if (redone) *redone = c->counters_redone;
+    if (margin) *margin = std::min(0.2, std::max(0.04, 3.0 * c->est_var));
+    if (row_max) *row_max = c->est_row_max;
+    return FOCR_OK;
 }
 
 int focr_ctx_set_size_estimates(focr_ctx_t *c, int on) {

@@ -262,15 +262,26 @@ struct VerifyArgs {
     const v4i *needles16;            // every template as n_h rows of 16 bytes (zero padded; two halves per row above 16 px)
     const uint32_t *needle16_row;    // class-ordered first row
     double thr_d;
+    uint32_t n_templates, n_pages, r_w, r_h;  // bounds of a well-formed key
+    unsigned long long *flags_word;           // d_res[4]: bit 2 = a key outside those bounds was met (internal error, never a fault)
 };
 VerifyArgs verify_args(const focr_ctx *c, double thr_d);  // scan_mfma.hip
-__device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs &va, float *sim_out) {
+// LDS: the whole of needles16 is staged in LDS at `lds` (rows.hip, verify_flat_kernel) — a compile-time choice, so that every
+// template-row load is a plain ds_read or a plain global load, never a per-lane choice between address spaces
+template <bool LDS>
+__device__ __forceinline__ bool verify_candidate_t(uint64_t key, const VerifyArgs &va, const v4i *lds, float *sim_out) {
     const uint32_t page = va.fmt.page(key), t = va.fmt.t(key), x = va.fmt.x(key), y = va.fmt.y(key);
+    if (t >= va.n_templates || page >= va.n_pages || x >= va.r_w || y >= va.r_h) {  // cannot happen; would otherwise be a wild read
+        atomicOr(va.flags_word, 4ull);
+        *sim_out = 0.f;
+        return false;
+    }
     const uint32_t ci = va.order_of[t];
     const TemplateConst c = va.tc[ci];
     // template rows: 16 bytes each, zero padded past n_w (two 16-byte halves per row for the 17..32-wide extension)
     const uint32_t halves = c.n_w > 16 ? 2 : 1;
-    const v4i *nd = va.needles16 + va.needle16_row[ci];
+    const uint32_t row0 = va.needle16_row[ci];
+    const v4i *nd = va.needles16 + row0;
     const uint8_t *pg = va.pages + ((size_t)page * va.rows_alloc + y) * va.pitch + x;  // rows have >= 64 readable bytes past r_w
     uint32_t acc = 0, s_p = 0, s2_p = 0;
     for (uint32_t hf = 0; hf < halves; hf++) {
@@ -283,7 +294,9 @@ __device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs 
 #pragma unroll 8
         for (uint32_t j = 0; j < c.n_h; j++) {
             const v4i a = *reinterpret_cast<const v4i_b1 *>(pg + (size_t)j * va.pitch + 16 * hf) & keep;
-            const v4i b = nd[j * halves + hf];
+            v4i b;
+            if (LDS) b = lds[row0 + j * halves + hf];
+            else b = nd[j * halves + hf];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
@@ -296,6 +309,9 @@ __device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs 
     const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
     *sim_out = (float)sim;
     return ncc_emits(sim, va.thr_d);
+}
+__device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs &va, float *sim_out) {
+    return verify_candidate_t<false>(key, va, nullptr, sim_out);
 }
 
 // Per-launch description of the threshold planes of the pass's size classes (scan_mfma2s_kernel).

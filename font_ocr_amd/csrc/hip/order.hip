@@ -193,7 +193,7 @@ static int ensure_matches(focr_ctx *c, size_t want) {
 // hits already sorted by the packed (page, y, x, t) key -> per-call lists + keep flags.  `n_p`: device-side number of
 // hits, `ub`: host-side upper bound the buffers and grids are sized for (exact sizes: ub == *n_p).  Leaves the result
 // sizes in c->d_res; no host wait.
-int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c) {
+static int order_sorted_hits_sort(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c) {
     const size_t n_seg = c->sub_np * c->n_templates;  // (page, template) calls of the pages being processed
     int rc;
     if ((rc = ensure_seg_arrays(c, c->n_pages * c->n_templates))) return rc;
@@ -222,6 +222,242 @@ int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t
                            c->d_seg_start, c->d_seg_offset, c->d_matches, keep);
         FOCR_HIP(c, hipGetLastError());
     }
+    hipLaunchKernelGGL(record_scan_sizes, dim3(1), dim3(1), 0, c->stream, n_cand_p, (uint64_t)ub_c, n_p, (uint64_t)ub, c->d_seg_offset + n_seg, c->d_res);
+    FOCR_HIP(c, hipGetLastError());
+    FOCR_HIP(c, hipMemcpyAsync(c->h_res, c->d_res, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    FOCR_HIP(c, hipEventRecord(c->ev[4], c->stream));
+    c->d_n_hits = n_p;
+    c->ub_hits = ub;
+    c->ordered = true;
+    return FOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same ordering pass without a sort ("counting" form, the default).  Hits are sorted by (page, y, x, t); a hit's place
+// in its (page, template) call is the number of earlier hits of the same page with the same t — a stable counting sort by t
+// inside each page, with T (templates) buckets:
+//   order_units    page boundaries by binary search; every page's hits are cut into units of ORDER_UNIT consecutive hits
+//   unit_hist      one wave per unit: histogram over t (LDS) -> uhist[unit][t]
+//   unit_prefix    one thread per (page, t): running sum over the page's units -> uhist becomes the unit's base rank;
+//                  the (page, t) total, capped, is the call's match count (src/ncc.cpp:225-227)
+//   prefix         match offsets (CSR) over the (page, t) calls
+//   unit_emit      one wave per unit, its hits 64 at a time, in order: rank = base + earlier hits of the same t in the unit
+//                  (lanes of one group with equal t are found with one ballot per bit of t) -> keep flag, match at its place
+// Six launches of a few microseconds each instead of ~14 (two radix passes over 2.7 M pairs with their histograms and scans,
+// binary-searched segment bounds, a library scan).  Banks with more than ORDER_T_MAX templates or batches with more than
+// 2^31 hits take the sorting form above.
+constexpr uint32_t ORDER_UNIT = 2048, ORDER_T_MAX = 4096;
+
+__global__ __launch_bounds__(1024) void order_units_kernel(const uint64_t *__restrict__ hkeys, const uint64_t *__restrict__ n_p, uint64_t ub, KeyFmt fmt,
+                                                           uint32_t page_base, uint32_t n_pages, uint32_t *__restrict__ page_start /* n_pages + 1 */,
+                                                           uint32_t *__restrict__ page_unit0 /* n_pages + 1 */, uint32_t *__restrict__ unit_page,
+                                                           uint32_t *__restrict__ unit_begin, uint32_t *__restrict__ unit_end) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s;
+    const uint64_t n = min(*n_p, ub);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 <= n_pages; p0 += 1024) {  // pages 1024 at a time (a batch rarely has more)
+        const uint32_t p = p0 + threadIdx.x;
+        uint32_t b = 0, e = 0, units = 0;
+        if (p < n_pages) {
+            b = (uint32_t)lower_bound_u64(hkeys, n, fmt.pack(page_base + p, 0, 0, 0));
+            e = (uint32_t)lower_bound_u64(hkeys, n, fmt.pack(page_base + p + 1, 0, 0, 0));
+            units = (e - b + ORDER_UNIT - 1) / ORDER_UNIT;
+            page_start[p] = b;
+        } else if (p == n_pages) {
+            page_start[p] = (uint32_t)n;
+        }
+        uint32_t incl = units;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += v;
+        }
+        if (lane == 63) wave_sum[wv] = incl;
+        __syncthreads();
+        uint32_t u0 = carry_s + incl - units;
+        for (uint32_t q = 0; q < wv; q++) u0 += wave_sum[q];
+        if (p <= n_pages) page_unit0[p] = u0;
+        for (uint32_t k = 0; k < units; k++) {
+            unit_page[u0 + k] = p;
+            unit_begin[u0 + k] = b + k * ORDER_UNIT;
+            unit_end[u0 + k] = min(e, b + (k + 1) * ORDER_UNIT);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = u0 + units;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void unit_hist_kernel(const uint64_t *__restrict__ hkeys, KeyFmt fmt, uint32_t T, const uint32_t *__restrict__ page_unit0,
+                                                        uint32_t n_pages, const uint32_t *__restrict__ unit_begin, const uint32_t *__restrict__ unit_end,
+                                                        uint32_t *__restrict__ uhist) {
+    extern __shared__ uint32_t hist_lds[];  // 4 waves x T
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *h = hist_lds + (size_t)wv * T;
+    const uint32_t n_units = page_unit0[n_pages], n_waves = gridDim.x * 4;
+    for (uint32_t u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv); u < n_units; u += n_waves) {
+        for (uint32_t i = lane; i < T; i += 64) h[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t b = unit_begin[u], e = unit_end[u];
+        for (uint32_t i = b + lane; i < e; i += 64) atomicAdd(&h[fmt.t(hkeys[i])], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t i = lane; i < T; i += 64) uhist[(size_t)u * T + i] = h[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+__global__ __launch_bounds__(256) void unit_prefix_kernel(uint32_t T, uint32_t n_pages, const uint32_t *__restrict__ page_unit0, uint32_t *__restrict__ uhist,
+                                                          uint32_t cap, uint32_t *__restrict__ seg_count, uint32_t n_seg_padded) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // (page, t) call
+    if (s >= n_seg_padded) return;
+    if (s >= n_pages * T) {  // the padding the prefix kernel reads 16 bytes at a time
+        seg_count[s] = 0;
+        return;
+    }
+    const uint32_t p = s / T, t = s % T;
+    uint32_t run = 0;
+    for (uint32_t u = page_unit0[p]; u < page_unit0[p + 1]; u++) {
+        const uint32_t v = uhist[(size_t)u * T + t];
+        uhist[(size_t)u * T + t] = run;
+        run += v;
+    }
+    seg_count[s] = min(run, cap);  // the reference stops the call at n_out matches (src/ncc.cpp:225-227)
+}
+
+// exclusive prefix of n u32 counts -> n + 1 u64 offsets, one workgroup, coalesced 16-byte loads (cnt padded with zeros to a
+// multiple of 4 entries behind n)
+typedef unsigned int ov4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void offsets_u64_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off) {
+    __shared__ uint64_t wave_sum[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t seg = ((n + 15) / 16 + 255) / 256 * 256, b = min(n, wv * seg), e = min(n, b + seg);
+    const ov4u *cnt4 = reinterpret_cast<const ov4u *>(cnt);
+    uint64_t sum = 0;
+    for (uint32_t i = b + 4 * lane; i < e; i += 256) {
+        const ov4u v = cnt4[i / 4];
+        sum += (uint64_t)v[0] + v[1] + v[2] + v[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) wave_sum[wv] = sum;
+    __syncthreads();
+    uint64_t carry = 0;
+    for (uint32_t q = 0; q < wv; q++) carry += wave_sum[q];
+    for (uint32_t i0 = b; i0 < e; i0 += 256) {
+        const uint32_t i = i0 + 4 * lane;
+        ov4u v = ov4u{0, 0, 0, 0};
+        if (i < e) v = cnt4[i / 4];
+        const uint64_t tot4 = (uint64_t)v[0] + v[1] + v[2] + v[3];
+        uint64_t incl = tot4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t u = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += u;
+        }
+        if (i < e) {
+            uint64_t p0 = carry + incl - tot4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i + k < n) off[i + k] = p0;
+                p0 += v[k];
+            }
+        }
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) {
+        uint64_t tot = 0;
+        for (int q = 0; q < 16; q++) tot += wave_sum[q];
+        off[n] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void unit_emit_kernel(const uint64_t *__restrict__ hkeys, const float *__restrict__ hsims, KeyFmt fmt, uint32_t T,
+                                                        uint32_t page_base, const uint32_t *__restrict__ page_unit0, uint32_t n_pages,
+                                                        const uint32_t *__restrict__ unit_page, const uint32_t *__restrict__ unit_begin,
+                                                        const uint32_t *__restrict__ unit_end, const uint32_t *__restrict__ uhist, uint32_t cap,
+                                                        const uint64_t *__restrict__ seg_offset, focr_match_t *__restrict__ out, uint8_t *__restrict__ keep) {
+    extern __shared__ uint32_t cnt_lds[];  // 4 waves x T: hits of each t seen so far in the unit
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *cnt = cnt_lds + (size_t)wv * T;
+    const uint32_t n_units = page_unit0[n_pages], n_waves = gridDim.x * 4;
+    const uint64_t lt_mask = (1ull << lane) - 1;
+    for (uint32_t u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv); u < n_units; u += n_waves) {
+        const uint32_t *ubase = uhist + (size_t)u * T;
+        for (uint32_t i = lane; i < T; i += 64) cnt[i] = ubase[i];  // the unit's base ranks
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t b = unit_begin[u], e = unit_end[u], p = unit_page[u];
+        for (uint32_t i0 = b; i0 < e; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < e;
+            const uint64_t k = valid ? hkeys[i] : 0;
+            const uint32_t t = valid ? fmt.t(k) : 0xffffffffu;
+            // lanes of this group with the same t: one ballot per bit of t
+            uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
+            for (uint32_t bit = 0; bit < fmt.bt; bit++) {
+                const bool one = (t >> bit) & 1;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(one);
+                peers &= one ? m : ~m;
+            }
+            if (valid) {
+                const uint32_t rank = cnt[t] + (uint32_t)__builtin_popcountll(peers & lt_mask);
+                const bool kept = rank < cap;
+                keep[i] = kept ? 1 : 0;
+                if (kept) {
+                    focr_match_t m;
+                    m.x = (uint16_t)fmt.x(k);
+                    m.y = (uint16_t)fmt.y(k);
+                    m.similarity = hsims[i];
+                    out[seg_offset[(size_t)p * T + t] + rank] = m;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // the highest lane of every peer group moves the counter on
+            if (valid && (peers >> lane) == 1ull) cnt[t] += (uint32_t)__builtin_popcountll(peers);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c) {
+    const uint32_t T = (uint32_t)c->n_templates, n_pages = (uint32_t)c->sub_np;
+    const size_t n_seg = (size_t)n_pages * T;
+    if (T > ORDER_T_MAX || ub >= ((size_t)1 << 31) || n_seg >= ((size_t)1 << 31)) return order_sorted_hits_sort(c, hkeys, hsims, n_p, ub, n_cand_p, ub_c);
+    int rc;
+    if ((rc = ensure_seg_arrays(c, c->n_pages * c->n_templates + 8))) return rc;
+    if ((rc = ensure_matches(c, ub))) return rc;  // matches <= hits
+    const size_t max_units = ub / ORDER_UNIT + n_pages + 1;
+    uint8_t *keep = (uint8_t *)c->ord_keep.ensure(c, ub + 1);
+    // unit tables: page_start, page_unit0 (n_pages + 1 each), unit_page / begin / end (max_units each)
+    uint32_t *tab = (uint32_t *)c->ord_v.ensure(c, (2 * ((size_t)n_pages + 1) + 3 * max_units) * 4);
+    uint32_t *uhist = (uint32_t *)c->ord_k2.ensure(c, max_units * T * 4);
+    if (!keep || !tab || !uhist) return fail(c, FOCR_ERR_NOMEM, "order: hipMalloc failed");
+    uint32_t *page_start = tab, *page_unit0 = tab + n_pages + 1, *unit_page = page_unit0 + n_pages + 1, *unit_begin = unit_page + max_units,
+             *unit_end = unit_begin + max_units;
+    c->d_hkeys = hkeys;
+    c->d_hsims = hsims;
+    hipDeviceProp_t prop;
+    FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    const unsigned unit_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((max_units + 3) / 4, (size_t)prop.multiProcessorCount * 4));
+    const size_t lds = (size_t)4 * T * 4;
+    hipLaunchKernelGGL(order_units_kernel, dim3(1), dim3(1024), 0, c->stream, hkeys, n_p, (uint64_t)ub, c->fmt, (uint32_t)c->sub_p0, n_pages, page_start, page_unit0,
+                       unit_page, unit_begin, unit_end);
+    FOCR_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(unit_hist_kernel, dim3(unit_blocks), dim3(256), lds, c->stream, hkeys, c->fmt, T, (const uint32_t *)page_unit0, n_pages,
+                       (const uint32_t *)unit_begin, (const uint32_t *)unit_end, uhist);
+    FOCR_HIP(c, hipGetLastError());
+    const uint32_t n_seg_padded = (uint32_t)((n_seg + 3) / 4 * 4 + 4);
+    hipLaunchKernelGGL(unit_prefix_kernel, dim3((n_seg_padded + 255) / 256), dim3(256), 0, c->stream, T, n_pages, (const uint32_t *)page_unit0, uhist, c->cap,
+                       c->d_seg_count, n_seg_padded);
+    FOCR_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(offsets_u64_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->d_seg_count, (uint32_t)n_seg, c->d_seg_offset);
+    FOCR_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(unit_emit_kernel, dim3(unit_blocks), dim3(256), lds, c->stream, hkeys, hsims, c->fmt, T, (uint32_t)c->sub_p0, (const uint32_t *)page_unit0,
+                       n_pages, (const uint32_t *)unit_page, (const uint32_t *)unit_begin, (const uint32_t *)unit_end, (const uint32_t *)uhist, c->cap,
+                       (const uint64_t *)c->d_seg_offset, c->d_matches, keep);
+    FOCR_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(record_scan_sizes, dim3(1), dim3(1), 0, c->stream, n_cand_p, (uint64_t)ub_c, n_p, (uint64_t)ub, c->d_seg_offset + n_seg, c->d_res);
     FOCR_HIP(c, hipGetLastError());
     FOCR_HIP(c, hipMemcpyAsync(c->h_res, c->d_res, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

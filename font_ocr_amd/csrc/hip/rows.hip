@@ -28,19 +28,22 @@ int ensure_hit_capacity(focr_ctx *c, size_t want);
 
 // exclusive prefix of n u32 counts by ONE workgroup: base[0..n] (base[n] = total); *total_out = total, *max_out = max
 // (u64 each; either may be null); zero[0..n) is cleared on the way if given (the scatter's per-row cursors).  Each of the 16
-// waves owns a contiguous segment and walks it 64 entries at a time (coalesced), twice: sums first, then the prefix.
+// waves owns a contiguous segment (a multiple of 256 entries) and walks it 256 entries at a time — 16-byte loads, coalesced
+// — twice: sums first, then the prefix.  The arrays are padded to a multiple of 4 entries by their owner (rows_begin).
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ base,
                                                           uint32_t *__restrict__ zero, uint64_t *__restrict__ total_out,
                                                           uint64_t *__restrict__ max_out) {
     __shared__ uint32_t wave_sum[16], wave_max[16];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t seg = ((n + 15) / 16 + 63) / 64 * 64, b = min(n, wv * seg), e = min(n, b + seg);
+    const uint32_t seg = ((n + 15) / 16 + 255) / 256 * 256, b = min(n, wv * seg), e = min(n, b + seg);
+    const v4u *cnt4 = reinterpret_cast<const v4u *>(cnt);
     uint32_t sum = 0, mx = 0;
-#pragma unroll 4
-    for (uint32_t i = b + lane; i < e; i += 64) {
-        const uint32_t v = cnt[i];
-        sum += v;
-        mx = max(mx, v);
+#pragma unroll 2
+    for (uint32_t i = b + 4 * lane; i < e; i += 256) {
+        const v4u v = cnt4[i / 4];  // entries past n (inside the padding) are zero
+        sum += v[0] + v[1] + v[2] + v[3];
+        mx = max(max(mx, max(v[0], v[1])), max(v[2], v[3]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -54,20 +57,26 @@ __global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__rest
     __syncthreads();
     uint32_t carry = 0;
     for (uint32_t q = 0; q < wv; q++) carry += wave_sum[q];
-    for (uint32_t i0 = b; i0 < e; i0 += 64) {
-        const uint32_t i = i0 + lane, v = i < e ? cnt[i] : 0;
-        uint32_t incl = v;
+#pragma unroll 2
+    for (uint32_t i0 = b; i0 < e; i0 += 256) {
+        const uint32_t i = i0 + 4 * lane;
+        v4u v = v4u{0, 0, 0, 0};
+        if (i < e) v = cnt4[i / 4];
+        const uint32_t tot4 = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = tot4;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t u = __shfl_up(incl, o);
             if ((int)lane >= o) incl += u;
         }
         if (i < e) {
-            base[i] = carry + incl - v;
-            if (zero) zero[i] = 0;
+            const uint32_t p0 = carry + incl - tot4;
+            reinterpret_cast<v4u *>(base)[i / 4] = v4u{p0, p0 + v[0], p0 + v[0] + v[1], p0 + v[0] + v[1] + v[2]};
+            if (zero) reinterpret_cast<v4u *>(zero)[i / 4] = v4u{0, 0, 0, 0};
         }
         carry += __shfl(incl, 63);
     }
+    __syncthreads();  // base[n] below may share a 16-byte group with the last wave's stores
     if (threadIdx.x == 0) {
         uint32_t tot = 0, m = 0;
         for (int q = 0; q < 16; q++) {
@@ -110,69 +119,121 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 }
 
 // Sort every row's candidates by (x, t) — the low bt + bx bits of the key, unique inside a row — in place.  One WAVE per row
-// (fixed stride: dense text rows are spread evenly over the waves), wave-private LDS, no workgroup barrier:
-//   counting sort by x-bin (bin = x >> xs, at most XBINS bins: one x per bin for pages up to 1024 px wide) — count, exclusive
-//   prefix, place — then every element finds its rank among the few elements of its own bin and goes straight back to the
-//   row's slots in global memory.  O(n) LDS operations per row instead of a bitonic network's O(n log^2 n).
-constexpr uint32_t XBINS = 1024;
-template <int CAP>
-__global__ __launch_bounds__(256) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
-                                                       uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t xs,
-                                                       uint32_t n_bins, unsigned long long *__restrict__ flags_word) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 cursors, CAP sub-keys
+// (fixed stride: dense text rows are spread evenly over the waves), wave-private LDS, no workgroup barrier: the row's
+// sub-keys come into LDS with all loads in flight at once, then a counting sort by x-bin (bin = x >> xs, at most XBINS bins:
+// one x per bin for pages up to 1024 px wide) — count, exclusive prefix, place — and every element finds its rank among the
+// few elements of its own bin and goes straight back to the row's slots in global memory.  O(n) LDS operations per row.
+//   LIST = false: all rows; a row above CAP goes onto `big` (BASELINE configs[1]: one or two rows per batch exceed 1024).
+//   LIST = true : the rows on `big`, with a larger CAP and one wave per workgroup; a row above that CAP sets the overflow bit
+//                 (batch redone through the legacy tail).
+constexpr uint32_t XBINS = 1024, BIG_ROWS_MAX = 4096;
+template <int CAP, int WAVES, bool LIST>
+__global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+                                                              uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t xs, uint32_t n_bins,
+                                                              uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 bin starts, CAP placed sub-keys
+    constexpr int K = CAP / 64;  // sub-keys per lane, in registers
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *cur = sort_lds + (size_t)wv * (XBINS + 1 + CAP) + 1;  // cur[-1] = 0: the start of bin 0
-    uint32_t *out = cur + XBINS;
-    const uint32_t wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+    uint32_t *cur = sort_lds + (size_t)wv * (XBINS + 1 + CAP);  // cur[n_bins] = n after the prefix
+    uint32_t *out = cur + XBINS + 1;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wv), n_waves = gridDim.x * WAVES;
     const uint64_t sub_mask = (1ull << sub_bits) - 1;
-    for (uint32_t r = wave; r < n_rows; r += n_waves) {
-        const uint32_t n = fill[r];
-        if (n < 2) continue;
-        if (n > (uint32_t)CAP) {  // the host sized the kernel from an estimate that did not hold: the batch is redone
-            if (lane == 0) atomicOr(flags_word, 2ull);
-            continue;
+    const uint32_t n_items = LIST ? min(big[0], BIG_ROWS_MAX) : n_rows;
+    // the next row's size and position are fetched (scalar loads) while the current row is sorted
+    uint32_t it = wave, r = 0, n = 0, b = 0;
+    if (it < n_items) {
+        r = LIST ? big[1 + it] : it;
+        n = fill[r];
+        b = base[r];
+    }
+    while (it < n_items) {
+        const uint32_t it2 = it + n_waves;
+        uint32_t r2 = 0, n2 = 0, b2 = 0;
+        if (it2 < n_items) {
+            r2 = LIST ? big[1 + it2] : it2;
+            n2 = fill[r2];
+            b2 = base[r2];
         }
-        uint64_t *row = bucket + base[r];
-        for (uint32_t i = lane; i <= n_bins; i += 64) cur[(int)i - 1] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t j = lane; j < n; j += 64) atomicAdd(&cur[(uint32_t)((row[j] & sub_mask) >> bt) >> xs], 1u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        uint32_t carry = 0;  // exclusive prefix over the bins, 64 at a time
-        for (uint32_t i0 = 0; i0 < n_bins; i0 += 64) {
-            const uint32_t i = i0 + lane, v = i < n_bins ? cur[i] : 0;
-            uint32_t incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
+        if (n > (uint32_t)CAP) {
+            if (lane == 0) {
+                if (LIST) {
+                    atomicOr(flags_word, 2ull);
+                } else {
+                    const uint32_t k = atomicAdd(big, 1u);
+                    if (k < BIG_ROWS_MAX) big[1 + k] = r;
+                    else atomicOr(flags_word, 2ull);
+                }
             }
-            if (i < n_bins) cur[i] = carry + incl - v;
-            carry += __shfl(incl, 63);
+        } else if (n >= 2) {
+            uint64_t *row = bucket + b;
+            uint32_t sub[K], slot[K], hi32 = 0, lo32 = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {  // all of the row's loads in flight at once
+                const uint32_t j = (uint32_t)lane + 64u * k;
+                sub[k] = 0;
+                if (64u * k < n && j < n) {
+                    const uint64_t key = row[j];
+                    sub[k] = (uint32_t)(key & sub_mask);
+                    if (k == 0) hi32 = (uint32_t)(key >> 32), lo32 = (uint32_t)key;
+                }
+            }
+            // (page, y) of the row from lane 0's first key (n >= 2: it has one)
+            const uint64_t high = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi32) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo32)) & ~sub_mask;  // the builtin returns int: no sign extension
+            for (uint32_t i = lane; i <= n_bins; i += 64) cur[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int k = 0; k < K; k++)  // count per x-bin; the returned value is the element's slot inside its bin
+                if (64u * k < n && (uint32_t)lane + 64u * k < n) slot[k] = atomicAdd(&cur[(sub[k] >> bt) >> xs], 1u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t carry = 0;  // exclusive prefix over the bins, 64 at a time; cur[n_bins] = n
+            for (uint32_t i0 = 0; i0 <= n_bins; i0 += 64) {
+                const uint32_t i = i0 + lane, v = i < n_bins ? cur[i] : 0;
+                uint32_t incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t u = __shfl_up(incl, o);
+                    if (lane >= o) incl += u;
+                }
+                if (i <= n_bins) cur[i] = carry + incl - v;
+                carry += __shfl(incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (64u * k < n && (uint32_t)lane + 64u * k < n) out[cur[(sub[k] >> bt) >> xs] + slot[k]] = sub[k];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (64u * k < n && (uint32_t)lane + 64u * k < n) {  // rank among the few elements of the same bin
+                    const uint32_t e = sub[k], bin = (e >> bt) >> xs, lo = cur[bin], hi = cur[bin + 1];
+                    uint32_t rank = 0;
+                    for (uint32_t i = lo; i < hi; i++) rank += out[i] < e;
+                    row[lo + rank] = high | e;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next row reuses the LDS buffers
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint64_t high = row[0] & ~sub_mask;  // (page, y): the same for the whole row
-        for (uint32_t j = lane; j < n; j += 64) {
-            const uint32_t sub = (uint32_t)(row[j] & sub_mask);
-            out[atomicAdd(&cur[(sub >> bt) >> xs], 1u)] = sub;  // cur[bin] ends up at the end of its bin
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t j = lane; j < n; j += 64) {
-            const uint32_t e = out[j], bin = (e >> bt) >> xs, lo = cur[(int)bin - 1], hi = cur[bin];
-            uint32_t rank = 0;
-            for (uint32_t i = lo; i < hi; i++) rank += out[i] < e;
-            row[lo + rank] = high | e;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next row reuses the LDS buffers
+        it = it2, r = r2, n = n2, b = b2;
     }
 }
 
-// exact verify, one thread per candidate of the row-ordered list (perfectly balanced); similarity + emit flag in place
-__global__ __launch_bounds__(256) void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
-                                                          const VerifyArgs va, float *__restrict__ bsims, uint8_t *__restrict__ bflags) {
+// exact verify, one thread per candidate of the row-ordered list (perfectly balanced); similarity + emit flag in place.
+// A candidate costs 15 page-row loads (neighbouring lanes: neighbouring windows, a few cache lines per wave instruction) and
+// 15 template-row loads — a 64-way GATHER per wave instruction when they come from global memory, which kept the texture
+// addresser busy for most of the kernel's time (round 2: 0.22 ms for 3.8 M candidates).  LDS = true: the bank's verify
+// operand (16 bytes per template row) is staged in LDS once per workgroup — when all of it fits 144 KiB (BASELINE
+// configs[1]: 380 templates, 91 KB); larger banks keep the global loads (LDS = false).
+template <bool LDS>
+__global__ __launch_bounds__(1024) void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
+                                                           const VerifyArgs va, uint32_t lds_rows, float *__restrict__ bsims, uint8_t *__restrict__ bflags) {
+    extern __shared__ __attribute__((aligned(16))) v4i needle_lds[];
+    if (LDS) {
+        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
+        __syncthreads();
+    }
     const unsigned long long n = min((unsigned long long)*total_p, cap);
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
         float sim;
-        const bool emit = verify_candidate(bucket[i], va, &sim);
+        const bool emit = verify_candidate_t<LDS>(bucket[i], va, needle_lds, &sim);
         bsims[i] = sim;
         bflags[i] = emit ? 1 : 0;
     }
@@ -236,11 +297,13 @@ bool rows_applicable(const focr_ctx *c) {
 // before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
 int rows_begin(focr_ctx *c) {
     const size_t n_rows = c->sub_np * c->r_h;
-    uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, (n_rows + 1) * 4);
-    if (!cnt || !c->rows_base.ensure(c, (n_rows + 1) * 4) || !c->rows_fill.ensure(c, (n_rows + 1) * 4) || !c->rows_hits.ensure(c, (n_rows + 1) * 4) ||
-        !c->rows_hbase.ensure(c, (n_rows + 1) * 4))
+    const size_t padded = (n_rows + 1 + 3) / 4 * 4 + 4;  // row_prefix_kernel moves 16 bytes at a time
+    uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, padded * 4);
+    if (!cnt || !c->rows_base.ensure(c, padded * 4) || !c->rows_fill.ensure(c, padded * 4) || !c->rows_hits.ensure(c, padded * 4) ||
+        !c->rows_hbase.ensure(c, padded * 4))
         return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    FOCR_HIP(c, hipMemsetAsync(cnt, 0, n_rows * 4, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(cnt, 0, padded * 4, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(c->rows_hits.p, 0, padded * 4, c->stream));  // the padding behind the last row must read 0
     c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0};
     return FOCR_OK;
 }
@@ -254,7 +317,7 @@ int rows_prefix(focr_ctx *c) {
     return FOCR_OK;
 }
 
-uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 256 ? 256u : row_max <= 1024 ? 1024u : row_max <= 4096 ? 4096u : 0u; }
+uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 4096 ? 4096u : 0u; }  // rows above 1024 take the second sort launch
 
 // scatter, per-row sort + verify, compaction: leaves the dense sorted hits in d_hit_keys / d_hit_sims_alt and their number in
 // d_res[6]; records ev[3] behind the verify
@@ -289,25 +352,37 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
     if (!bflags) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
     const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
     {
-        const uint32_t cap = cap_class <= 256 ? 256 : cap_class <= 1024 ? 1024 : 4096;
-        const size_t lds = (size_t)4 * (XBINS + 1 + cap) * 4;
         uint32_t xs = 0;
         while (((uint32_t)c->r_w >> xs) + 1 > XBINS) xs++;
         const uint32_t n_bins = ((uint32_t)c->r_w >> xs) + 1;
-        auto launch = [&](auto kern) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(row_blocks), dim3(256), lds, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx,
-                               c->fmt.bt, xs, n_bins, flags_word);
-        };
-        if (cap == 256) launch(row_sort_kernel<256>);
-        else if (cap == 1024) launch(row_sort_kernel<1024>);
-        else launch(row_sort_kernel<4096>);
+        uint32_t *big = (uint32_t *)c->rows_big.ensure(c, (BIG_ROWS_MAX + 1) * 4);
+        if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+        FOCR_HIP(c, hipMemsetAsync(big, 0, 4, c->stream));
+        auto k1 = row_sort_kernel<1024, 4, false>;
+        auto k2 = row_sort_kernel<4096, 1, true>;
+        const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
+        hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
+                           xs, n_bins, big, flags_word);
+        FOCR_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k2, dim3(64), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, xs, n_bins,
+                           big, flags_word);
         FOCR_HIP(c, hipGetLastError());
     }
     if (ub_c) {
-        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 64);
-        hipLaunchKernelGGL(verify_flat_kernel, dim3(nb), dim3(256), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va, bsims,
-                           bflags);
+        // the verify operand in LDS if all of it fits
+        size_t all_rows = 0;
+        for (const TemplateConst &tc : c->h_tconst) all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
+        const bool in_lds = all_rows * 16 <= ((size_t)144 << 10);
+        const size_t lds = in_lds ? all_rows * 16 : 0;
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + 1023) / 1024, (size_t)cus));
+        if (in_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(1024), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
+                               (uint32_t)all_rows, bsims, bflags);
+        } else {
+            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * 4), dim3(1024), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
+                               va, 0u, bsims, bflags);
+        }
         FOCR_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(row_pack_kernel, dim3(row_blocks), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, bsims, (const uint8_t *)bflags,

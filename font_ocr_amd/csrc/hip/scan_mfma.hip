@@ -512,7 +512,8 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
 
 VerifyArgs verify_args(const focr_ctx *c, double thr_d) {
     return VerifyArgs{c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of, c->d_tconst,
-                      reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d};
+                      reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, (uint32_t)c->n_templates, (uint32_t)c->n_pages,
+                      (uint32_t)c->r_w, (uint32_t)c->r_h, (unsigned long long *)(c->d_res + 4)};
 }
 
 // Process-wide hand-over of the scan kernel between contexts of one device (events are never destroyed).
@@ -635,7 +636,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (!su.mtx) continue;
             uint8_t *lv = live + su.live_offset;
             std::vector<char> done(su.classes.size(), 0);
-            for (size_t v = 0; v < su.classes.size(); v++) {
+            std::vector<size_t> order;  // classes whose last column is dropped first: they can take their kept box along
+            for (int pass = 0; pass < 2; pass++)
+                for (size_t v = 0; v < su.classes.size(); v++)
+                    if ((c->classes[su.classes[v]].keep_w != c->classes[su.classes[v]].n_w) == (pass == 0)) order.push_back(v);
+            for (size_t v : order) {
                 if (done[v]) continue;
                 const size_t k = su.classes[v];
                 const SizeClass &sc = c->classes[k];

@@ -188,6 +188,12 @@ class Scanner:
         """focr_ctx_set_size_estimates: repeat scans of one setup queue every phase without host waits (default on)."""
         self._ck(self._lib.focr_ctx_set_size_estimates(self._h, int(bool(on))))
 
+    def size_estimate_stats(self):
+        """focr_size_estimate_stats: {'redone': batches redone with exact sizes, 'margin': next estimate's margin, 'row_max': ...}."""
+        r, m, x = C.c_uint64(), C.c_double(), C.c_uint32()
+        self._ck(self._lib.focr_size_estimate_stats(self._h, C.byref(r), C.byref(m), C.byref(x)))
+        return {"redone": int(r.value), "margin": float(m.value), "row_max": int(x.value)}
+
     def force_split(self, on):
         """Test hook (focr_debug_force_split): scan the batch in page sub-ranges as after a candidate overflow."""
         self._ck(self._lib.focr_debug_force_split(self._h, int(bool(on))))
