@@ -9,8 +9,10 @@ post-processed match lists to rank 0.  Workload = BASELINE configs[1]: 128 pages
 no data-path collective other than that final gather (weak scaling: per-GPU work fixed).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N ...                      # launches N ranks itself (one process per GPU) when RANK / WORLD_SIZE are unset
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W        # or under an external launcher
+  python bench.py --gpus 8 --config c4              # BASELINE configs[3]: 8192 pages sharded over the ranks + RCCL gather
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the MFMA prefilter launch with the
 most work), timed live with HIP events on the stream it runs on; `cpu_baseline` times the reference's
@@ -61,6 +63,75 @@ def effective_cpus():
     return n
 
 
+def self_launch(args):
+    """`--gpus N` (N > 1) without a launcher's RANK / WORLD_SIZE: start the N ranks here, one child process per GPU, before
+    anything in this process has touched the GPU (a process that has initialised HIP must not exec or fork GPU users).
+    Rank 0's JSON line is this process's stdout; any rank failing fails the run."""
+    import socket
+    import subprocess
+
+    if not args.dry_launch:
+        import torch  # counting devices does not initialise the GPU
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine shows {have} GPU(s); refusing to measure fewer GPUs than asked for\n")
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return 0
+
+
+def dry_run(args, rank, world, real_stdout):
+    """`--dry-launch`: the launcher, the rendezvous, the barrier-bracketed timing, the MAX over ranks and the rank census on
+    the gloo backend with a stub step — no GPU, no scan.  What tests/test_bench_launch.py runs on the CPU; never a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = args.pages_per_gpu
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))  # ranks differ: the job's time is the slowest rank's
+    dt_local = time.perf_counter() - t0
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    seen = torch.tensor([1], dtype=torch.int64)
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([P * R_W * R_H * args.steps / dt_local / 1e6], dtype=torch.float64)
+    every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(every, mine)
+    if rank == 0:
+        out = {"metric": "Mpixels/s scanned (95-glyph x --x-bits=2 bank)", "value": round(world * P * R_W * R_H * args.steps / dt / 1e6, 2), "unit": "Mpx/s",
+               "n_gpus": world, "ranks_seen": int(seen.item()), "per_rank_value": [round(float(v.item()), 2) for v in every], "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "none", "data": "none", "dry_launch": True,
+               "config": {"workload": "DRY LAUNCH: stub step on the gloo backend, no GPU — exercises the rank launcher and the timing protocol only"}}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     # ROCm maps a process's streams onto 4 hardware queues by default; three contexts + the gather's streams + RCCL's
     # are more than that, and a small copy sharing a queue with a context waits behind its 2.5 ms scan kernel
@@ -89,7 +160,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pages", type=int, default=0, help="0 = 4 pages per host thread")
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
-    ap.add_argument("--with-upload", action="store_true", help="also time steps that start from host pages (PCIe-inclusive rate, reported as e2e_*)")
+    ap.add_argument("--with-upload", action="store_true", help="also time steps that start from PAGEABLE host pages, upload and scan back to back (e2e_value_incl_h2d)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the short untimed leg that measures the pipelined PCIe-inclusive rate (e2e_value_incl_h2d_pipelined)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher / timing-protocol self-test on the gloo backend with a stub step: no GPU, not a measurement")
     ap.add_argument("--settle-s", type=float, default=0.4, help="untimed extra warm-up (seconds of steps) before the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     ap.add_argument("--scan-cus", type=int, default=-1,
@@ -100,6 +173,8 @@ def main():
                          "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
                          "overlap another's MFMA scan; 1 = strictly one batch at a time")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     # Exactly ONE line may reach stdout (the JSON).  RCCL prints a version banner to stdout at init, so park
     # the real stdout and point fd 1 at stderr for everything else (Python and native code alike).
@@ -114,8 +189,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:  # never measure another number of GPUs than the one asked for
+        os.write(2, f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n".encode())
+        raise SystemExit(2)
+    if args.dry_launch:
+        return dry_run(args, rank, world, real_stdout)
 
     import torch
     import torch.distributed as dist
@@ -299,7 +377,7 @@ def main():
             t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, device_ptr=device_ptr, shape=shape)
         jobs.append(t)
 
-    def fence():
+    def fence(barrier=True):
         nonlocal n_chars
         while jobs:
             retire()
@@ -312,9 +390,9 @@ def main():
         for c_ in scs:
             c_.sync()
         torch.cuda.synchronize()
-        if use_dist:
+        if use_dist and barrier:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # Untimed: the W warm-up steps, then — still untimed — more of the same steps until ~0.4 s of device work has gone by:
     # the first scan of every context reads its result sizes synchronously (later ones run on those sizes), buffers grow to
@@ -338,19 +416,35 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    fence(barrier=False)
+    dt_own = time.perf_counter() - t0  # this rank's own work done (per_rank_value); the job's time includes the barrier
     fence()
     dt = time.perf_counter() - t0
     timed = False
+    dt_local = dt_own
+    ranks_seen, per_rank = 1, None
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        seen = torch.tensor([1], device=dev, dtype=torch.int64)  # rank census over the nccl group: the line is for exactly this many GPUs
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen = int(seen.item())
 
     total_px = (args.c4_pages if shard is not None else world * P) * R_W * R_H * args.steps
     value = total_px / dt / 1e6
+    if use_dist:  # every rank's own rate (its pages over its own time)
+        my_pages = (n_mine if shard is not None else P) * args.steps
+        mine = torch.tensor([my_pages * R_W * R_H / dt_local / 1e6], device=dev, dtype=torch.float64)
+        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(v.item()), 2) for v in every]
+    # what the size estimates did during the timed region: the bench rescans the same resident batches every step, so the
+    # estimates are at their best case (smallest margin, nothing redone); --config c4 streams different batches
+    est = [c_.size_estimate_stats() for c_ in scs]
     e2e = e2e_pipe = None
-    if args.with_upload:  # PCIe-inclusive rates (never the headline value)
-        # (1) every step starts from pageable host memory, upload and scan back to back on one context
+    e2e_steps = 0
+    if args.with_upload and shard is None:  # PCIe-inclusive, pageable host memory, upload and scan back to back on one context
         fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -358,9 +452,11 @@ def main():
             run_step(sc)
         fence()
         e2e = total_px / (time.perf_counter() - t1) / 1e6
-        # (2) pipelined ingest: every step starts from page-locked host memory; the same contexts / host threads as
-        #     the headline run, each uploading its batch (one asynchronous DMA + inversion kernel on its stream)
-        #     before scanning it, so batch k+1's copy runs under batch k's scan
+    if not args.no_e2e and shard is None and not use_dist:
+        # SURVEY.md section 8(d) asks for both timings: device-resident (`value`) and end to end.  A short extra leg outside the
+        # timed region: every step starts from PAGE-LOCKED HOST memory; the same contexts / host threads as the headline run,
+        # each uploading its batch (one asynchronous DMA + inversion kernel on its stream) before scanning it, so batch k+1's
+        # copy crosses PCIe under batch k's scan.  Never the headline value.
         from font_ocr_amd.searcher import PinnedPages
 
         pins = []
@@ -382,12 +478,13 @@ def main():
                 pipe.wait(t)
                 pipe.release(t)
 
-        pipe_steps(n_ctx)
+        pipe_steps(2 * n_ctx)
         fence()
+        e2e_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 30))
         t1 = time.perf_counter()
-        pipe_steps(args.steps)
+        pipe_steps(e2e_steps)
         fence()
-        e2e_pipe = total_px / (time.perf_counter() - t1) / 1e6
+        e2e_pipe = P * R_W * R_H * e2e_steps / (time.perf_counter() - t1) / 1e6
         for pin in pins:
             pin.close()
     counters = sc.counters()
@@ -411,6 +508,7 @@ def main():
         "value": round(value, 2),
         "unit": "Mpx/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -441,7 +539,15 @@ def main():
     }
     if e2e is not None:
         out["e2e_value_incl_h2d"] = round(e2e, 2)
+    if e2e_pipe is not None:
         out["e2e_value_incl_h2d_pipelined"] = round(e2e_pipe, 2)
+        out["e2e_note"] = (f"extra untimed leg of {e2e_steps} steps: every batch starts in page-locked host memory and crosses PCIe (one DMA per batch) "
+                           "under the previous batch's scan; `value` is the device-resident rate")
+    out["size_estimates"] = {"batches_redone_exact": sum(e["redone"] for e in est), "margin": est[0]["margin"], "largest_page_row": est[0]["row_max"],
+                             "note": "every step rescans the same resident batches, so the result-size estimates run at their smallest margin "
+                                     "with nothing redone; different batches per step: --config c4"}
+    if per_rank is not None:
+        out["per_rank_value"] = per_rank
     if args.noise:
         out["data"] = "uniform random noise pages (worst case, no hits)"
     if rank == 0:

@@ -389,10 +389,17 @@ __global__ __launch_bounds__(256) void unit_emit_kernel(const uint64_t *__restri
         for (uint32_t i = lane; i < T; i += 64) cnt[i] = ubase[i];  // the unit's base ranks
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t b = unit_begin[u], e = unit_end[u], p = unit_page[u];
+        uint64_t k_next = b + lane < e ? hkeys[b + lane] : 0;  // the next group's key and similarity are loaded a group ahead
+        float s_next = b + lane < e ? hsims[b + lane] : 0.f;
         for (uint32_t i0 = b; i0 < e; i0 += 64) {
             const uint32_t i = i0 + lane;
             const bool valid = i < e;
-            const uint64_t k = valid ? hkeys[i] : 0;
+            const uint64_t k = k_next;
+            const float sim = s_next;
+            if (i + 64 < e) {
+                k_next = hkeys[i + 64];
+                s_next = hsims[i + 64];
+            }
             const uint32_t t = valid ? fmt.t(k) : 0xffffffffu;
             // lanes of this group with the same t: one ballot per bit of t
             uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(256) void unit_emit_kernel(const uint64_t *__restri
                     focr_match_t m;
                     m.x = (uint16_t)fmt.x(k);
                     m.y = (uint16_t)fmt.y(k);
-                    m.similarity = hsims[i];
+                    m.similarity = sim;
                     out[seg_offset[(size_t)p * T + t] + rank] = m;
                 }
             }

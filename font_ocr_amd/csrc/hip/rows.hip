@@ -39,11 +39,18 @@ __global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__rest
     const uint32_t seg = ((n + 15) / 16 + 255) / 256 * 256, b = min(n, wv * seg), e = min(n, b + seg);
     const v4u *cnt4 = reinterpret_cast<const v4u *>(cnt);
     uint32_t sum = 0, mx = 0;
-#pragma unroll 2
-    for (uint32_t i = b + 4 * lane; i < e; i += 256) {
-        const v4u v = cnt4[i / 4];  // entries past n (inside the padding) are zero
-        sum += v[0] + v[1] + v[2] + v[3];
-        mx = max(max(mx, max(v[0], v[1])), max(v[2], v[3]));
+    for (uint32_t i0 = b + 4 * lane; i0 < e; i0 += 4 * 256) {
+        v4u vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            vv[q] = v4u{0, 0, 0, 0};
+            if (i0 + q * 256 < e) vv[q] = cnt4[(i0 + q * 256) / 4];  // entries past n (inside the padding) are zero
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sum += vv[q][0] + vv[q][1] + vv[q][2] + vv[q][3];
+            mx = max(max(mx, max(vv[q][0], vv[q][1])), max(vv[q][2], vv[q][3]));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -57,24 +64,32 @@ __global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__rest
     __syncthreads();
     uint32_t carry = 0;
     for (uint32_t q = 0; q < wv; q++) carry += wave_sum[q];
-#pragma unroll 2
-    for (uint32_t i0 = b; i0 < e; i0 += 256) {
-        const uint32_t i = i0 + 4 * lane;
-        v4u v = v4u{0, 0, 0, 0};
-        if (i < e) v = cnt4[i / 4];
-        const uint32_t tot4 = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = tot4;
+    for (uint32_t i00 = b; i00 < e; i00 += 4 * 256) {  // four tiles' loads in flight, then their scans
+        v4u vv[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += u;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = i00 + q * 256 + 4 * lane;
+            vv[q] = v4u{0, 0, 0, 0};
+            if (i < e) vv[q] = cnt4[i / 4];
         }
-        if (i < e) {
-            const uint32_t p0 = carry + incl - tot4;
-            reinterpret_cast<v4u *>(base)[i / 4] = v4u{p0, p0 + v[0], p0 + v[0] + v[1], p0 + v[0] + v[1] + v[2]};
-            if (zero) reinterpret_cast<v4u *>(zero)[i / 4] = v4u{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = i00 + q * 256 + 4 * lane;
+            const v4u v = vv[q];
+            const uint32_t tot4 = v[0] + v[1] + v[2] + v[3];
+            uint32_t incl = tot4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += u;
+            }
+            if (i < e) {
+                const uint32_t p0 = carry + incl - tot4;
+                reinterpret_cast<v4u *>(base)[i / 4] = v4u{p0, p0 + v[0], p0 + v[0] + v[1], p0 + v[0] + v[1] + v[2]};
+                if (zero) reinterpret_cast<v4u *>(zero)[i / 4] = v4u{0, 0, 0, 0};
+            }
+            carry += __shfl(incl, 63);
         }
-        carry += __shfl(incl, 63);
     }
     __syncthreads();  // base[n] below may share a 16-byte group with the last wave's stores
     if (threadIdx.x == 0) {
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 //   LIST = false: all rows; a row above CAP goes onto `big` (BASELINE configs[1]: one or two rows per batch exceed 1024).
 //   LIST = true : the rows on `big`, with a larger CAP and one wave per workgroup; a row above that CAP sets the overflow bit
 //                 (batch redone through the legacy tail).
-constexpr uint32_t XBINS = 1024, BIG_ROWS_MAX = 4096;
+constexpr uint32_t XBINS = 1024;
 template <int CAP, int WAVES, bool LIST>
 __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
                                                               uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t xs, uint32_t n_bins,
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
     uint32_t *out = cur + XBINS + 1;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wv), n_waves = gridDim.x * WAVES;
     const uint64_t sub_mask = (1ull << sub_bits) - 1;
-    const uint32_t n_items = LIST ? min(big[0], BIG_ROWS_MAX) : n_rows;
+    const uint32_t n_items = LIST ? min(big[0], n_rows) : n_rows;  // the list has room for every row
     // the next row's size and position are fetched (scalar loads) while the current row is sorted
     uint32_t it = wave, r = 0, n = 0, b = 0;
     if (it < n_items) {
@@ -159,24 +174,22 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
                 if (LIST) {
                     atomicOr(flags_word, 2ull);
                 } else {
-                    const uint32_t k = atomicAdd(big, 1u);
-                    if (k < BIG_ROWS_MAX) big[1 + k] = r;
-                    else atomicOr(flags_word, 2ull);
+                    big[1 + atomicAdd(big, 1u)] = r;  // room for every row
                 }
             }
         } else if (n >= 2) {
             uint64_t *row = bucket + b;
-            uint32_t sub[K], slot[K], hi32 = 0, lo32 = 0;
+            uint32_t sub[K], slot[K];
+            uint64_t key[K];
 #pragma unroll
-            for (int k = 0; k < K; k++) {  // all of the row's loads in flight at once
+            for (int k = 0; k < K; k++) {  // all of the row's loads in flight at once: nothing but loads in this loop
                 const uint32_t j = (uint32_t)lane + 64u * k;
-                sub[k] = 0;
-                if (64u * k < n && j < n) {
-                    const uint64_t key = row[j];
-                    sub[k] = (uint32_t)(key & sub_mask);
-                    if (k == 0) hi32 = (uint32_t)(key >> 32), lo32 = (uint32_t)key;
-                }
+                key[k] = 0;
+                if (64u * k < n) key[k] = row[j < n ? j : n - 1];  // wave-uniform branch; lanes past the end re-read the last key
             }
+#pragma unroll
+            for (int k = 0; k < K; k++) sub[k] = (uint32_t)(key[k] & sub_mask);
+            const uint32_t hi32 = (uint32_t)(key[0] >> 32), lo32 = (uint32_t)key[0];
             // (page, y) of the row from lane 0's first key (n >= 2: it has one)
             const uint64_t high = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi32) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lo32)) & ~sub_mask;  // the builtin returns int: no sign extension
             for (uint32_t i = lane; i <= n_bins; i += 64) cur[i] = 0;
@@ -355,7 +368,7 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         uint32_t xs = 0;
         while (((uint32_t)c->r_w >> xs) + 1 > XBINS) xs++;
         const uint32_t n_bins = ((uint32_t)c->r_w >> xs) + 1;
-        uint32_t *big = (uint32_t *)c->rows_big.ensure(c, (BIG_ROWS_MAX + 1) * 4);
+        uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4);
         if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
         FOCR_HIP(c, hipMemsetAsync(big, 0, 4, c->stream));
         auto k1 = row_sort_kernel<1024, 4, false>;
@@ -364,7 +377,7 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
                            xs, n_bins, big, flags_word);
         FOCR_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k2, dim3(64), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, xs, n_bins,
+        hipLaunchKernelGGL(k2, dim3(cus), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, xs, n_bins,
                            big, flags_word);
         FOCR_HIP(c, hipGetLastError());
     }

@@ -487,7 +487,9 @@ template <int OUT>
 static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out, void *out_pair, uint32_t Lpitch, uint32_t Lrows, uint8_t *live,
                         uint32_t mtx, uint32_t n_rows) {
     const SizeClass &sc = c->classes[k];
-    dim3 grid(Lpitch / STX, (Lrows + STY - 1) / STY, (unsigned)c->sub_np);
+    // only what the scan kernels read: the windows of the pass's M-tiles (x < 16 * mtx) in the searched rows (y <= n_rows)
+    dim3 grid(std::min<unsigned>(Lpitch / STX, (16 * mtx + STX - 1) / STX), std::min<unsigned>((Lrows + STY - 1) / STY, (n_rows + 1 + STY - 1) / STY),
+              (unsigned)c->sub_np);
     StatsOut A{plane_params(c, k, thr_d), out}, B{};
     if (pair >= 0) B = StatsOut{plane_params(c, (size_t)pair, thr_d), out_pair};
     const bool drop = sc.keep_w != sc.n_w, small = sc.n_w * sc.n_h <= 256;
