@@ -36,9 +36,9 @@ PEAK_I8_MFMA_TOPS = 5000.0  # dense i8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense pea
 
 def traffic_of(kernel_name, workload):
     """HBM-side bytes per launch of the dominant kernel, taken from committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
-    separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) — only when a profile exists for exactly this kernel and
-    this workload (pages per launch, geometry, templates); otherwise None: a live run cannot read PMC counters, and a
-    number measured for another kernel or workload would be stale.  Returns (bytes, source file) or (None, None)."""
+    separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md) — only when a profile exists for exactly this kernel (name
+    AND source hash) and this workload (pages per launch, geometry, templates); otherwise None: a live run cannot read PMC
+    counters, and a number measured for another kernel or workload would be stale.  Returns (bytes, source file) or (None, None)."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
@@ -47,6 +47,18 @@ def traffic_of(kernel_name, workload):
         except (OSError, ValueError):
             continue
         if t.get("kernel") == kernel_name and all(t.get("workload_key", {}).get(k) == v for k, v in workload.items()):
+            # ... and for exactly this kernel BODY: the profile records a hash of the kernel's sources (a changed kernel with the same
+            # name and workload would otherwise inherit a stale number)
+            import hashlib
+
+            h = hashlib.sha256()
+            try:
+                for src in t.get("kernel_sources", []):
+                    h.update(open(os.path.join(ROOT, src), "rb").read())
+            except OSError:
+                continue
+            if t.get("kernel_source_sha16") != h.hexdigest()[:16]:
+                continue
             return t.get("traffic_bytes"), os.path.relpath(path, ROOT)
     return None, None
 

@@ -184,6 +184,12 @@ std::string utf8_encode(uint32_t cp) {
     return s;
 }
 
+std::string f32s(float v);
+std::string f32dbg(float v) {  // Rust `{:?}` of an f32: as `{}`, with ".0" on whole numbers
+    std::string t = f32s(v);
+    if (t.find_first_of(".eEn") == std::string::npos) t += ".0";  // n: inf / NaN
+    return t;
+}
 std::string f32s(float v) {  // Rust `{}` of an f32
     char buf[64];
     focr_format_f32(v, buf, sizeof buf);
@@ -230,7 +236,11 @@ bool write_png_gray(const std::string &path, const uint8_t *px, uint32_t w, uint
 
 [[noreturn]] void die(const std::string &msg) {
     fprintf(stderr, "ncc: %s\n", msg.c_str());
-    exit(101);  // a Rust panic's exit status
+    // a Rust panic's exit status.  _exit, not exit: once the fleet exists its worker threads may be inside HIP calls, and
+    // running the HIP runtime's atexit handlers / static destructors under them can hang or crash instead of returning 101
+    fflush(stdout);
+    fflush(stderr);
+    _exit(101);
 }
 
 #define CK(ctx, expr)                                                        \
@@ -268,6 +278,20 @@ int main(int argc, char **argv) {
         die(std::string("rasterising the template bank failed: ") + err);
     clk.lap("bank raster");
     if (args.verbose) {
+        // the reference's preamble, src/ncc.rs:791-802: font.metrics() and what follows from it at --text-size
+        focr_font_metrics_t fm{};
+        if (focr_font_metrics(args.font.c_str(), &fm, err, sizeof err) != 0) die(std::string("font metrics: ") + err);
+        const float to_px = (1.f / (float)fm.units_per_em) * args.text_size;
+        const float line_space = fm.ascent - fm.descent + fm.line_gap;
+        fprintf(stderr, "metrics Metrics { units_per_em: %u, ascent: %s, descent: %s, line_gap: %s, underline_position: %s, underline_thickness: %s, "
+                        "cap_height: %s, x_height: %s, bounding_box: RectF(<%s, %s>, <%s, %s>) }\n",
+                fm.units_per_em, f32dbg(fm.ascent).c_str(), f32dbg(fm.descent).c_str(), f32dbg(fm.line_gap).c_str(), f32dbg(fm.underline_position).c_str(),
+                f32dbg(fm.underline_thickness).c_str(), f32dbg(fm.cap_height).c_str(), f32dbg(fm.x_height).c_str(), f32s(fm.bbox[0]).c_str(),
+                f32s(fm.bbox[1]).c_str(), f32s(fm.bbox[2]).c_str(), f32s(fm.bbox[3]).c_str());
+        fprintf(stderr, "ascent  %spx\n", f32s(fm.ascent * to_px).c_str());
+        fprintf(stderr, "descent %spx\n", f32s(fm.descent * to_px).c_str());
+        fprintf(stderr, "font_bbox size <%s, %s>px\n", f32s(fm.bbox[2] * to_px - fm.bbox[0] * to_px).c_str(), f32s(fm.bbox[3] * to_px - fm.bbox[1] * to_px).c_str());
+        fprintf(stderr, "line_space %s %spx\n", f32s(line_space).c_str(), f32s(line_space * to_px).c_str());
         fprintf(stderr, "bank: %zu templates (%zu letters x %u x %u sub-pixel offsets), advance %spx\n", bank.n_templates,
                 alphabet.size(), 1u << args.x_bits, 1u << args.y_bits, f32s(bank.advance_px).c_str());
     }

@@ -641,6 +641,11 @@ static int scan_now(focr_ctx *c) {
         c->sizes_pending = false;
         rc = scan_split(c, run);
         if (rc) return rc;
+        // the sub-runs left the size estimates at the counts of the LAST page sub-range: a following scan of this setup must
+        // not run "estimated" on them (it would overflow, redo exact, overflow again and only then split)
+        c->est_cand = c->est_hits = 0;
+        c->est_last_cand = c->est_last_hits = 0;
+        c->est_row_max = 0;
     } else if (rc) {
         return rc;
     }

@@ -2,6 +2,7 @@
 // node"; SURVEY.md section 8e at the product level, src/ncc.rs:839-847).  One focr_pipe per device; batch k goes to device
 // k % n_devices.  A device's pipe sees every n_devices-th batch in order, so the pipe's own ticket of fleet ticket T is
 // (T - 1) / n_devices + 1 and nothing has to be looked up.
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -15,6 +16,7 @@ struct focr_fleet {
     unsigned lanes = 0;
     std::mutex mu;  // serialises submit: tickets are handed out in submission order
     uint64_t next_ticket = 1;
+    std::atomic<uint64_t> released{0};  // tickets given back with focr_fleet_release
 };
 
 using focr::fail;
@@ -104,13 +106,23 @@ int focr_fleet_set_fetch(focr_fleet_t *f, int on) {
 int focr_fleet_submit(focr_fleet_t *f, const void *pages, int pages_on_device, size_t n_pages, size_t r_w, size_t r_h, int invert, float threshold,
                       uint32_t cap, int mode, int process_hits, float anchor_threshold, int32_t overlap, uint64_t *ticket) {
     if (!f || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_submit: bad arguments");
-    std::lock_guard<std::mutex> lk(f->mu);  // held while the target lane is busy: submissions are ordered by definition
+    std::lock_guard<std::mutex> lk(f->mu);  // submissions are ordered by definition
     const uint64_t t = f->next_ticket;
+    // Every lane holding an unreleased batch: the lane this batch maps to is the one with the OLDEST ticket, and waiting for it
+    // here would be waiting for the caller's own focr_fleet_release — a consumer that submits and retires on one thread would
+    // hang with no diagnostic.  Refuse instead (a consumer that releases from a second thread simply submits again).
+    if (t - 1 - f->released.load() >= (uint64_t)f->pipes.size() * f->lanes)
+        return fail(nullptr, FOCR_ERR_STATE, "focr_fleet_submit: every lane holds an unreleased batch; release the oldest ticket first");
     uint64_t pt = 0;
     const int rc = focr_pipe_submit(pipe_of(f, t), pages, pages_on_device, n_pages, r_w, r_h, invert, threshold, cap, mode, process_hits, anchor_threshold,
                                     overlap, nullptr, 0, &pt);
     if (rc != FOCR_OK) return rc;
-    if (pt != pipe_ticket(f, t)) return fail(nullptr, FOCR_ERR_STATE, "focr_fleet_submit: a pipe of the fleet was submitted to directly");
+    if (pt != pipe_ticket(f, t)) {  // somebody used the pipe behind the fleet's back: do not leave the stray job queued on it
+        focr_ctx_t *ctx = nullptr;
+        (void)focr_pipe_wait(pipe_of(f, t), pt, &ctx);
+        (void)focr_pipe_release(pipe_of(f, t), pt);
+        return fail(nullptr, FOCR_ERR_STATE, "focr_fleet_submit: a pipe of the fleet was submitted to directly");
+    }
     f->next_ticket++;
     *ticket = t;
     return FOCR_OK;
@@ -128,7 +140,9 @@ int focr_fleet_host_results(focr_fleet_t *f, uint64_t ticket, focr_host_results_
 
 int focr_fleet_release(focr_fleet_t *f, uint64_t ticket) {
     if (!f || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_release: bad arguments");
-    return focr_pipe_release(pipe_of(f, ticket), pipe_ticket(f, ticket));
+    const int rc = focr_pipe_release(pipe_of(f, ticket), pipe_ticket(f, ticket));
+    if (rc == FOCR_OK) f->released.fetch_add(1);
+    return rc;
 }
 
 }  // extern "C"

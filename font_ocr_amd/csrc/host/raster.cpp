@@ -23,6 +23,7 @@
 
 #include <ft2build.h>
 #include FT_FREETYPE_H
+#include FT_TRUETYPE_TABLES_H
 
 #include "focr_host.h"
 
@@ -227,5 +228,34 @@ extern "C" int focr_raster_bank(const char *font_path, float text_size, uint32_t
     out->y_bits = y_bits;
     out->text_size = text_size;
     out->advance_px = advance_px;
+    return 0;
+}
+
+// font.metrics() as font-kit's FreeType loader reports it (src/ncc.rs:791-802 prints it under -v); from memory, unpinned
+extern "C" int focr_font_metrics(const char *font_path, focr_font_metrics_t *out, char *err, size_t errlen) {
+    auto fail = [&](const char *m) {
+        if (err && errlen) snprintf(err, errlen, "%s", m);
+        return 1;
+    };
+    if (!font_path || !out) return fail("focr_font_metrics: bad arguments");
+    Face f;
+    if (FT_Init_FreeType(&f.lib) != 0) return fail("FT_Init_FreeType failed");
+    if (FT_New_Face(f.lib, font_path, 0, &f.face) != 0) return fail("cannot open font");  // Font::from_path(..).unwrap(), src/ncc.rs:792
+    const FT_Face fc = f.face;
+    memset(out, 0, sizeof *out);
+    out->units_per_em = fc->units_per_EM;
+    out->ascent = (float)fc->ascender;
+    out->descent = (float)fc->descender;
+    out->line_gap = (float)(fc->height + fc->descender - fc->ascender);
+    out->underline_position = (float)(fc->underline_position + fc->underline_thickness / 2);
+    out->underline_thickness = (float)fc->underline_thickness;
+    if (const TT_OS2 *os2 = (const TT_OS2 *)FT_Get_Sfnt_Table(fc, FT_SFNT_OS2)) {
+        out->cap_height = (float)os2->sCapHeight;
+        out->x_height = (float)os2->sxHeight;
+    }
+    out->bbox[0] = (float)fc->bbox.xMin;
+    out->bbox[1] = (float)fc->bbox.yMin;
+    out->bbox[2] = (float)fc->bbox.xMax;
+    out->bbox[3] = (float)fc->bbox.yMax;
     return 0;
 }

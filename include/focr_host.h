@@ -42,6 +42,18 @@ int focr_raster_bank(const char *font_path, float text_size, uint32_t x_bits, ui
                      uint32_t x_padding, uint32_t y_padding, focr_bank_t *out, char *err,
                      size_t errlen);
 
+/* font.metrics() of the reference's font-kit loader (src/ncc.rs:791-802, the `ncc -v` preamble), in font units:
+ * units_per_em, ascent, descent (negative below the baseline), line_gap, underline position / thickness, cap height,
+ * x height, bounding box (origin x, y, lower-right x, y).  Restated from font-kit 0.14's FreeType loader from memory
+ * (ascender, descender, height + descender - ascender, OS/2 sCapHeight / sxHeight): parity unpinned.  Returns 0 or non-zero
+ * with a message in err. */
+typedef struct focr_font_metrics {
+    uint32_t units_per_em;
+    float ascent, descent, line_gap, underline_position, underline_thickness, cap_height, x_height;
+    float bbox[4];
+} focr_font_metrics_t;
+int focr_font_metrics(const char *font_path, focr_font_metrics_t *out, char *err, size_t errlen);
+
 void focr_bank_free(focr_bank_t *bank);
 int focr_bank_save(const char *path, const focr_bank_t *bank);
 int focr_bank_load(const char *path, focr_bank_t *out);

@@ -62,7 +62,14 @@ typedef struct focr_match {
  *
  * Thread-safe: each calling thread gets its own device stream and staging
  * buffers.  No error channel exists in the reference signature; on a device
- * failure these return 0 and focr_last_error_global() describes it. */
+ * failure these return 0 and focr_last_error_global() describes it.
+ * Residency: the reference's host calls these once per template with the SAME
+ * page and window tables, so a thread's inputs stay on the device and are sent
+ * again only when a 64-bit content hash (non-cryptographic) of an input or the
+ * geometry changes — a hash collision between two different inputs of one
+ * geometry (~2^-64 per pair) would reuse the stale copy.
+ * FOCR_COMPAT_ALWAYS_UPLOAD=1 in the environment disables it (every call
+ * uploads every input). */
 size_t ncc_8_u8(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *needle_u8, size_t n_w,
                 size_t n_h, uint32_t *acc, size_t acc_len, uint32_t *patch_sum,
                 double *patch_rnorm, uint16_t *start_end, float threshold, focr_match_t *out,
@@ -314,8 +321,9 @@ int focr_pipe_release(focr_pipe_t *pipe, uint64_t ticket);
  * device k % n_devices and, there, to the next lane.  Tickets are the fleet's own, 1, 2, 3 ... in submission order; retire
  * them in that order and the output order is the submission order whatever the device count.  No collective: results
  * converge on the host that consumes them (a device-resident consumer uses focr_rccl.h).  `devices` == NULL or
- * n_devices == 0: all visible devices.  focr_fleet_submit blocks while the lane the batch maps to still holds an
- * unreleased batch (at most n_devices * lanes_per_device batches are in flight); with pages_on_device != 0 the pointer
+ * n_devices == 0: all visible devices.  At most n_devices * lanes_per_device batches are in flight: with every lane holding
+ * an unreleased batch focr_fleet_submit returns FOCR_ERR_STATE ("release the oldest ticket first") instead of waiting for a
+ * release that a single-threaded consumer could never make; with pages_on_device != 0 the pointer
  * must belong to focr_fleet_device_of(ticket it will get) — host pages are the normal case.  The `ncc` binary is this
  * loop. */
 typedef struct focr_fleet focr_fleet_t;
