@@ -11,11 +11,12 @@
 //   row_sort<CAP>     one WAVE per row, wave-private LDS: counting sort by x, rank inside the x-bin by t — in place
 //   verify_flat       the reference arithmetic on every candidate (verify_candidate, mfma_common.h), one thread each: the
 //                     row-ordered list is dense, neighbouring lanes read the same page lines
-//   row_pack          one wave per row: the survivors to the front of the row's slots, order kept; the row's hit count
+//                     (it also counts the hits of every row)
 //   row_prefix        exclusive prefix of the rows' hit counts -> the dense position of every row's hits, the hit total
-//   row_compact       rows -> dense (key, similarity) arrays in (page, y, x, t) order      what order.hip takes over
+//   row_compact       one wave per row: the survivors, order kept, to dense (key, similarity) arrays in (page, y, x, t) order
+//                     — what order.hip takes over
 //
-// Eight small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A row with more candidates than the
+// Seven small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A row with more candidates than the
 // instantiated capacity (the host picks 256 / 1024 / 4096 from the largest row: exact mode knows it, estimated mode takes the
 // previous scan's) sets the overflow bit and the batch is redone; rows beyond 4096 candidates (very low thresholds) and
 // banks with tall classes take the legacy tail (scan_mfma.hip: radix sort + verify_kernel + compaction).
@@ -177,6 +178,18 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
                     big[1 + atomicAdd(big, 1u)] = r;  // room for every row
                 }
             }
+        } else if (n >= 2 && n <= 64 && !LIST) {
+            // a row that fits one key per lane (most rows that are not text lines): rank by comparing with every other lane's key
+            // — no LDS, no bins; keys are unique, so the rank is the key's place
+            uint64_t *row = bucket + b;
+            const uint64_t key = row[(uint32_t)lane < n ? lane : n - 1];
+            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) {  // j is wave-uniform: v_readlane
+                const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, (int)j);
+                rank += other < key;
+            }
+            if ((uint32_t)lane < n) row[rank] = key;
         } else if (n >= 2) {
             uint64_t *row = bucket + b;
             uint32_t sub[K], slot[K];
@@ -237,63 +250,64 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
 // configs[1]: 380 templates, 91 KB); larger banks keep the global loads (LDS = false).
 template <bool LDS>
 __global__ __launch_bounds__(1024) void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
-                                                           const VerifyArgs va, uint32_t lds_rows, float *__restrict__ bsims, uint8_t *__restrict__ bflags) {
+                                                           const VerifyArgs va, uint32_t lds_rows, const RowHist rows, float *__restrict__ bsims,
+                                                           uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
     extern __shared__ __attribute__((aligned(16))) v4i needle_lds[];
     if (LDS) {
         for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
         __syncthreads();
     }
     const unsigned long long n = min((unsigned long long)*total_p, cap);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        float sim;
-        const bool emit = verify_candidate_t<LDS>(bucket[i], va, needle_lds, &sim);
-        bsims[i] = sim;
-        bflags[i] = emit ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {  // wave-uniform trip count
+        const unsigned long long i = i0 + lane;
+        const bool valid = i < n;
+        const uint64_t key = valid ? bucket[i] : 0;
+        float sim = 0.f;
+        const bool emit = valid && verify_candidate_t<LDS>(key, va, needle_lds, &sim);
+        if (valid) {
+            bsims[i] = sim;
+            bflags[i] = emit ? 1 : 0;
+        }
+        // hits per page row: the wave's 64 consecutive candidates belong to one row, rarely two or three
+        const uint32_t r = emit ? row_of_key(key, rows) : 0xffffffffu;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(emit);
+        while (todo) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
+            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
+            if (lane == (int)__builtin_ctzll(peers)) atomicAdd(row_hits + r0, (uint32_t)__builtin_popcountll(peers));
+            todo &= ~peers;
+        }
     }
 }
 
-// survivors of a row to the front of its slots (order kept), one wave per row; row_hits[r] = their number
-__global__ __launch_bounds__(256) void row_pack_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
-                                                       uint64_t *__restrict__ bucket, float *__restrict__ bsims, const uint8_t *__restrict__ bflags,
-                                                       uint32_t *__restrict__ row_hits) {
+// survivors of every row, order kept, to their dense places: hbase[r] (exclusive prefix of the rows' hit counts) + rank inside
+// the row.  One wave per row.
+__global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+                                                          const uint32_t *__restrict__ hbase, const uint64_t *__restrict__ bucket,
+                                                          const float *__restrict__ bsims, const uint8_t *__restrict__ bflags, uint64_t *__restrict__ hkeys,
+                                                          float *__restrict__ hsims, unsigned long long hit_cap) {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = gridDim.x * 4;
     for (uint32_t r = wave; r < n_rows; r += n_waves) {
         const uint32_t n = fill[r];
+        if (n == 0) continue;
         const size_t b = base[r];
-        uint32_t nh = 0;
+        size_t dst = hbase[r];
         for (uint32_t j0 = 0; j0 < n; j0 += 64) {
             const uint32_t j = j0 + lane;
-            const bool valid = j < n;
-            const uint64_t key = valid ? bucket[b + j] : 0;
-            const float sim = valid ? bsims[b + j] : 0.f;
-            const bool emit = valid && bflags[b + j];
+            const bool emit = j < n && bflags[b + j];
             const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
-            if (emit) {  // position <= b + j: only slots this wave has already read are overwritten
-                const uint32_t pos = nh + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                bucket[b + pos] = key;
-                bsims[b + pos] = sim;
+            if (emit) {
+                const size_t pos = dst + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (pos < hit_cap) {  // estimated sizes: a hit count above its bound is flagged by record_scan_sizes and redone
+                    hkeys[pos] = bucket[b + j];
+                    hsims[pos] = bsims[b + j];
+                }
             }
-            nh += (uint32_t)__builtin_popcountll(mask);
+            dst += (size_t)__builtin_popcountll(mask);
         }
-        if (lane == 0) row_hits[r] = nh;
-    }
-}
-
-__global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ row_hits,
-                                                          const uint32_t *__restrict__ hbase, const uint64_t *__restrict__ bucket,
-                                                          const float *__restrict__ bsims, uint64_t *__restrict__ hkeys, float *__restrict__ hsims,
-                                                          unsigned long long hit_cap) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    for (uint32_t r = wave; r < n_rows; r += n_waves) {
-        const uint32_t n = row_hits[r];
-        const size_t src = base[r], dst = hbase[r];
-        for (uint32_t j = lane; j < n; j += 64)
-            if (dst + j < hit_cap) {  // estimated sizes: a hit count above its bound is flagged by record_scan_sizes and redone
-                hkeys[dst + j] = bucket[src + j];
-                hsims[dst + j] = bsims[src + j];
-            }
     }
 }
 
@@ -391,24 +405,22 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         if (in_lds) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(1024), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
-                               (uint32_t)all_rows, bsims, bflags);
+                               (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
         } else {
             hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * 4), dim3(1024), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
-                               va, 0u, bsims, bflags);
+                               va, 0u, c->row_hist, bsims, bflags, hits);
         }
         FOCR_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(row_pack_kernel, dim3(row_blocks), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, bsims, (const uint8_t *)bflags,
-                       hits);
-    FOCR_HIP(c, hipGetLastError());
     FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
     hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6,
                        (uint64_t *)nullptr);
     FOCR_HIP(c, hipGetLastError());
     {
         const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
-        hipLaunchKernelGGL(row_compact_kernel, dim3(nb), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)hits, (const uint32_t *)hbase,
-                           (const uint64_t *)c->d_cand_alt, (const float *)bsims, c->d_hit_keys, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+        hipLaunchKernelGGL(row_compact_kernel, dim3(nb), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)fill, (const uint32_t *)hbase,
+                           (const uint64_t *)c->d_cand_alt, (const float *)bsims, (const uint8_t *)bflags, c->d_hit_keys, c->d_hit_sims_alt,
+                           (unsigned long long)c->hit_capacity);
         FOCR_HIP(c, hipGetLastError());
     }
     return FOCR_OK;

@@ -101,6 +101,9 @@ def test_cli_batched_pipeline_is_order_preserving(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout == "".join(l + "\n" for l in outs[0].splitlines() if int(l.split(",")[0]) < 2)
     assert r.stderr.count("needle size") == 2 * len(alphabet) and "hits: " in r.stderr and "overall " in r.stderr
+    # ... preceded by the reference's font-metrics preamble (src/ncc.rs:791-802)
+    for line in ("metrics Metrics { units_per_em: 2048, ascent: 1901.0, descent: -483.0,", "ascent  ", "descent -", "font_bbox size <", "line_space 2384 "):
+        assert line in r.stderr, (line, r.stderr[:600])
 
 
 @pytest.mark.skipif(not os.path.exists(FONT), reason="DejaVu Sans Mono not installed")

@@ -965,6 +965,11 @@ def test_fleet_orders_batches_over_devices(bank_x2):
 
             for k, pg in enumerate(batches):
                 if len(inflight) == fl.n_devices * fl.lanes:
+                    if k == fl.n_devices * fl.lanes:  # every lane holds an unreleased batch: refused, not a silent self-deadlock
+                        from font_ocr_amd.searcher import FocrError
+
+                        with pytest.raises(FocrError, match="release the oldest"):
+                            fl.submit(pg, 0.8, 1024, SCAN_MFMA, True, 0.95, 5)
                     retire()
                 t = fl.submit(pg, 0.8, 1024, SCAN_MFMA, True, 0.95, 5)
                 assert t == k + 1
