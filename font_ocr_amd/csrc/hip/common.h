@@ -73,18 +73,23 @@ struct KeyFmt {
     __host__ __device__ uint64_t line(uint64_t k) const { return k >> (bt + bx); }  // (page << by) | y
 };
 
-// Per-(page, row) candidate counts for the row path of the tail (rows.hip): every candidate a wave flushes also counts
-// towards its page row (one no-return atomic per candidate; a flush's 64 keys come from a dozen rows).  cnt == nullptr: off.
+// Candidate counts per BUCKET for the row path of the tail (rows.hip).  A bucket is a page row cut into n_seg segments of
+// 2^seg_shift pixels (x >> seg_shift): one segment for narrow pages and small banks, more where a whole row would hold
+// more candidates than one wave sorts in LDS (BASELINE configs[2]: 1200-px rows x 1520 templates).  Buckets ascend with the
+// key: (page, y, x-segment).  Every candidate a wave flushes counts towards its bucket — one no-return atomic per distinct
+// bucket among the flushed keys.  cnt == nullptr: off.
 struct RowHist {
-    uint32_t *cnt;       // [sub_np * r_h], zeroed at the start of the scan
+    uint32_t *cnt;       // [sub_np * r_h * n_seg], zeroed at the start of the scan
     uint32_t r_h;
     uint32_t shift;      // bt + bx: key >> shift = (page << by) | y   (at most 32 bits)
     uint32_t by;
     uint32_t page_base;  // first page of the sub-batch (keys carry absolute page numbers)
+    uint32_t bt, bx;     // x = (key >> bt) & (2^bx - 1)
+    uint32_t seg_shift, n_seg;
 };
 __host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
-    const uint32_t line = (uint32_t)(key >> h.shift);
-    return ((line >> h.by) - h.page_base) * h.r_h + (line & ((1u << h.by) - 1u));
+    const uint32_t line = (uint32_t)(key >> h.shift), x = (uint32_t)(key >> h.bt) & ((1u << h.bx) - 1u);
+    return (((line >> h.by) - h.page_base) * h.r_h + (line & ((1u << h.by) - 1u))) * h.n_seg + (x >> h.seg_shift);
 }
 
 }  // namespace focr
@@ -198,6 +203,7 @@ struct focr_ctx {
     DevBuf rows_cnt, rows_base, rows_fill, rows_hits, rows_hbase, rows_big;
     uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
     uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
+    uint32_t row_seg_shift = 0; // log2 of the x-segment width of the buckets (0: not chosen yet for this setup; rows.hip, row_segments)
     bool rows_enabled = true;   // focr_ctx_set_tail(): false = always the legacy tail (radix sort + verify + compaction)
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch

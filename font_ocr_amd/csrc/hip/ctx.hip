@@ -653,6 +653,8 @@ static int scan_now(focr_ctx *c) {
     return FOCR_OK;
 }
 
+void row_segments(const focr_ctx *c, uint32_t *seg_shift, uint32_t *n_seg);  // rows.hip
+
 int finish_results(focr_ctx *c) {
     if (!c->sizes_pending && !c->post_pending) return FOCR_OK;
     FOCR_HIP(c, hipSetDevice(c->device));
@@ -704,6 +706,12 @@ int finish_results(focr_ctx *c) {
             c->est_cand = (size_t)n_cand + (size_t)((double)n_cand * margin) + 8192;
             c->est_hits = (size_t)n_hits + (size_t)((double)n_hits * margin) + 8192;
             c->est_row_max = c->row_cap ? (uint32_t)std::max<uint64_t>(c->h_res[5], 1) : 0;  // 0: the last scan took the legacy tail
+            {  // buckets still well above what a wave sorts in registers: halve the x-segments for the next scan of this setup
+                uint32_t sh, ns;
+                row_segments(c, &sh, &ns);
+                c->row_seg_shift = sh;
+                if (c->h_res[5] > 2048 && sh > 5) c->row_seg_shift = sh - 1;
+            }
         }
         c->counters[1] = n_hits;
         c->n_hits = c->n_hits_raw = (size_t)n_hits;
@@ -759,6 +767,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         sig = (sig ^ v) * 1099511628211ull;
     if (sig != c->est_sig) {
         c->est_row_max = 0;
+        c->row_seg_shift = 0;
         c->est_cand = c->est_hits = 0;
         c->est_var = 0.0667;
         c->est_last_cand = c->est_last_hits = 0;

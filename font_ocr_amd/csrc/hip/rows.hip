@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 constexpr uint32_t XBINS = 1024;
 template <int CAP, int WAVES, bool LIST>
 __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
-                                                              uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t xs, uint32_t n_bins,
+                                                              uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t seg_mask, uint32_t xs, uint32_t n_bins,
                                                               uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 bin starts, CAP placed sub-keys
     constexpr int K = CAP / 64;  // sub-keys per lane, in registers
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int k = 0; k < K; k++)  // count per x-bin; the returned value is the element's slot inside its bin
-                if (64u * k < n && (uint32_t)lane + 64u * k < n) slot[k] = atomicAdd(&cur[(sub[k] >> bt) >> xs], 1u);
+                if (64u * k < n && (uint32_t)lane + 64u * k < n) slot[k] = atomicAdd(&cur[((sub[k] >> bt) & seg_mask) >> xs], 1u);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             uint32_t carry = 0;  // exclusive prefix over the bins, 64 at a time; cur[n_bins] = n
             for (uint32_t i0 = 0; i0 <= n_bins; i0 += 64) {
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int k = 0; k < K; k++)
-                if (64u * k < n && (uint32_t)lane + 64u * k < n) out[cur[(sub[k] >> bt) >> xs] + slot[k]] = sub[k];
+                if (64u * k < n && (uint32_t)lane + 64u * k < n) out[cur[((sub[k] >> bt) & seg_mask) >> xs] + slot[k]] = sub[k];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if (64u * k < n && (uint32_t)lane + 64u * k < n) {  // rank among the few elements of the same bin
-                    const uint32_t e = sub[k], bin = (e >> bt) >> xs, lo = cur[bin], hi = cur[bin + 1];
+                    const uint32_t e = sub[k], bin = ((e >> bt) & seg_mask) >> xs, lo = cur[bin], hi = cur[bin + 1];
                     uint32_t rank = 0;
                     for (uint32_t i = lo; i < hi; i++) rank += out[i] < e;
                     row[lo + rank] = high | e;
@@ -314,16 +314,37 @@ __global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const
 // ---------------------------------------------------------------------------------------------
 // host side
 
+// x-segments per page row: a bucket should hold what one wave sorts in registers (<= 1024 candidates; up to 4096 go through
+// the second, slower launch).  Candidates per row grow with the row's windows x templates: the first scan of a setup takes one
+// segment per <= 2^19 of them (BASELINE configs[1]: 608 x 380 -> one segment, a row or two per batch just above 1024;
+// configs[2]: 1200 x 1520 -> 5 segments of 256 px), later scans halve the segments while the largest bucket stays above 2048
+// (ctx.hip, finish_results: configs[2] settles at 128 px).  The segmentation never changes a result.
+void row_segments(const focr_ctx *c, uint32_t *seg_shift, uint32_t *n_seg) {
+    uint32_t sh = c->row_seg_shift;
+    if (!sh) {
+        while (((size_t)1 << sh) < c->r_w) sh++;  // one segment
+        while (sh > 5 && ((size_t)1 << sh) * c->n_templates > ((size_t)1 << 19)) sh--;
+    }
+    *seg_shift = sh;
+    *n_seg = (uint32_t)((c->r_w + ((size_t)1 << sh) - 1) >> sh);
+}
+
+static size_t row_buckets(const focr_ctx *c) {
+    uint32_t sh, ns;
+    row_segments(c, &sh, &ns);
+    return c->sub_np * c->r_h * ns;
+}
+
 bool rows_applicable(const focr_ctx *c) {
     if (!c->rows_enabled) return false;
     for (const SizeClass &sc : c->classes)
-        if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per row
-    return c->sub_np * c->r_h <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32;
+        if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per bucket
+    return row_buckets(c) <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32;
 }
 
 // before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
 int rows_begin(focr_ctx *c) {
-    const size_t n_rows = c->sub_np * c->r_h;
+    const size_t n_rows = row_buckets(c);  // "rows" below: buckets = page rows x x-segments
     const size_t padded = (n_rows + 1 + 3) / 4 * 4 + 4;  // row_prefix_kernel moves 16 bytes at a time
     uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, padded * 4);
     if (!cnt || !c->rows_base.ensure(c, padded * 4) || !c->rows_fill.ensure(c, padded * 4) || !c->rows_hits.ensure(c, padded * 4) ||
@@ -331,13 +352,15 @@ int rows_begin(focr_ctx *c) {
         return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
     FOCR_HIP(c, hipMemsetAsync(cnt, 0, padded * 4, c->stream));
     FOCR_HIP(c, hipMemsetAsync(c->rows_hits.p, 0, padded * 4, c->stream));  // the padding behind the last row must read 0
-    c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0};
+    uint32_t seg_shift, n_seg;
+    row_segments(c, &seg_shift, &n_seg);
+    c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0, c->fmt.bt, c->fmt.bx, seg_shift, n_seg};
     return FOCR_OK;
 }
 
 // right after the scan kernels: row_base, cursors cleared, the largest row -> d_res[5]
 int rows_prefix(focr_ctx *c) {
-    const uint32_t n_rows = (uint32_t)(c->sub_np * c->r_h);
+    const uint32_t n_rows = (uint32_t)row_buckets(c);
     hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->rows_cnt.p, n_rows, (uint32_t *)c->rows_base.p,
                        (uint32_t *)c->rows_fill.p, (uint64_t *)nullptr, c->d_res + 5);
     FOCR_HIP(c, hipGetLastError());
@@ -349,7 +372,7 @@ uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 4096 ? 4096u : 
 // scatter, per-row sort + verify, compaction: leaves the dense sorted hits in d_hit_keys / d_hit_sims_alt and their number in
 // d_res[6]; records ev[3] behind the verify
 int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class) {
-    const uint32_t n_rows = (uint32_t)(c->sub_np * c->r_h);
+    const uint32_t n_rows = (uint32_t)row_buckets(c);
     int rc;
     if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
     if (c->cand_alt_capacity < c->cand_capacity) {
@@ -379,9 +402,10 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
     if (!bflags) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
     const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
     {
+        const uint32_t seg_w = 1u << c->row_hist.seg_shift;
         uint32_t xs = 0;
-        while (((uint32_t)c->r_w >> xs) + 1 > XBINS) xs++;
-        const uint32_t n_bins = ((uint32_t)c->r_w >> xs) + 1;
+        while ((seg_w >> xs) > XBINS) xs++;
+        const uint32_t n_bins = seg_w >> xs;
         uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4);
         if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
         FOCR_HIP(c, hipMemsetAsync(big, 0, 4, c->stream));
@@ -389,9 +413,9 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         auto k2 = row_sort_kernel<4096, 1, true>;
         const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
         hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
-                           xs, n_bins, big, flags_word);
+                           seg_w - 1, xs, n_bins, big, flags_word);
         FOCR_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k2, dim3(cus), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, xs, n_bins,
+        hipLaunchKernelGGL(k2, dim3(cus), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
                            big, flags_word);
         FOCR_HIP(c, hipGetLastError());
     }
