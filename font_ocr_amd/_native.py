@@ -169,6 +169,7 @@ HOST_SYMBOLS = {
 RASTER_SYMBOLS = {
     "focr_raster_bank": (C.c_int, [C.c_char_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
                                    C.c_int, C.c_uint32, C.c_uint32, C.POINTER(BankStruct), C.c_char_p, C.c_size_t]),
+    "focr_font_metrics": (C.c_int, [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]),
 }
 
 # include/focr_rccl.h (libfocr_rccl.so)

@@ -100,14 +100,30 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     uint32_t (*H2)[STX] = reinterpret_cast<uint32_t (*)[STX]>(stats_lds + rows * SLDW);
     uint16_t (*H)[STX] = reinterpret_cast<uint16_t (*)[STX]>(stats_lds + rows * (SLDW + STX));  // row sums <= 16 * 255
     const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
+    uint32_t any_ink = 0;
     for (uint32_t i = threadIdx.x; i < rows * SLDW; i += 256) {
         uint32_t r = i / SLDW, cdw = i % SLDW;
         uint32_t gy = y0 + r, gx = x0 + cdw * 4;
         uint32_t v = 0;
         if (gy < rows_alloc && gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t *>(pg + (size_t)gy * pitch + gx);
         tile[r][cdw] = v;
+        any_ink |= v;
     }
-    __syncthreads();
+    // Blank paper under the whole tile (page margins: ~1 block in 10): every window here has zero variance — "never emits",
+    // no M-tile marked live — so the sliding sums are skipped and the entries just say so (an M-tile of this block can still be
+    // live through another size class of the pass, whose launch stages a wider tile: its reads must find a defined value).
+    if (!__syncthreads_or((int)(any_ink != 0))) {
+        const uint32_t col = threadIdx.x & 63, x = x0 + col;
+        if (x < Lpitch)
+            for (uint32_t k = 0; k < STY / 4; k++) {
+                const uint32_t y = y0 + (threadIdx.x >> 6) * (STY / 4) + k;
+                if (y >= Lrows) break;
+                const size_t idx = ((size_t)page * Lrows + y) * Lpitch + x;
+                stats_store<OUT>(A, idx, false, 0.f);
+                if (PAIR) stats_store<OUT>(B, idx, false, 0.f);
+            }
+        return;
+    }
     {  // horizontal sums
         const uint32_t lane = threadIdx.x & 63, cb = lane >> 2, sh = lane & 3;
         for (uint32_t r = threadIdx.x >> 6; r < rows; r += 4) {
