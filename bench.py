@@ -178,8 +178,8 @@ def main():
     ap.add_argument("--settle-s", type=float, default=0.4, help="untimed extra warm-up (seconds of steps) before the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     ap.add_argument("--scan-cus", type=int, default=-1,
-                    help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 3/4 "
-                         "of them (the rest is left to the other contexts' small kernels; profiles/r02_cu_sweep.log)")
+                    help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
+                         "of them (the rest is left to the other contexts' small kernels; flat optimum 192..224 of 256: DESIGN.md section 5)")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
                          "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
@@ -233,7 +233,7 @@ def main():
     P = args.pages_per_gpu
     n_ctx = max(1, args.in_flight)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_ctx == 1 else n_cus - n_cus // 4)
+    scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_ctx == 1 else n_cus - n_cus // 8)
     # The executor: n_ctx contexts with a native worker thread each (focr_pipe_*, include/focr_ncc.h)
     from font_ocr_amd.searcher import Pipeline
 

@@ -155,6 +155,8 @@ struct focr_ctx {
     size_t pages_capacity = 0;  // pages d_pages was allocated for (>= n_pages)
     unsigned scan_cus = 0;      // CUs the persistent scan kernel may occupy, 0 = all (focr_ctx_set_scan_cus)
     uint8_t *d_pages = nullptr;
+    uint8_t *d_pages_i8 = nullptr;  // the same pages as int8 (ink - 128, i.e. byte ^ 0x80; padding = 0x80): the MFMA prefilter's window operand,
+                                    // written at ingest so that the scan kernels need no v_xor per fragment dword
     uint8_t *d_stage = nullptr;  // device staging for uploads
     size_t stage_bytes = 0;
 

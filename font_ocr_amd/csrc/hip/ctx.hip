@@ -23,14 +23,17 @@ int fail(focr_ctx *ctx, int code, const std::string &msg) {
 }
 
 // tight luma8 pages -> pitched ink-high pages (image_to_u8, src/ncc.rs:887-892, on the device)
-__global__ void ingest_pages(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t r_w, size_t r_h,
+__global__ void ingest_pages(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint8_t *__restrict__ dst_i8, size_t r_w, size_t r_h,
                              size_t pitch, size_t rows_alloc, size_t first, size_t count, int invert) {
     size_t total = count * r_h * r_w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t p = i / (r_h * r_w), rem = i % (r_h * r_w);
         size_t y = rem / r_w, x = rem % r_w;
         uint8_t v = src[i];
-        dst[((first + p) * rows_alloc + y) * pitch + x] = invert ? (uint8_t)(255 - v) : v;
+        v = invert ? (uint8_t)(255 - v) : v;
+        const size_t o = ((first + p) * rows_alloc + y) * pitch + x;
+        dst[o] = v;
+        dst_i8[o] = v ^ 0x80;  // ink - 128 as int8: the prefilter's operand (its templates sum to zero, so the bias cancels exactly)
     }
 }
 
@@ -246,6 +249,7 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     free_bank(c);
     free_results(c);
     free_dev(c->d_pages);
+    free_dev(c->d_pages_i8);
     free_dev(c->d_stage);
     free_dev(c->d_counter);
     free_dev(c->d_res);
@@ -440,6 +444,7 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
     }
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_pages);
+    free_dev(c->d_pages_i8);
     c->pages_capacity = 0;
     c->scanned = c->processed = false;
     c->n_pages = n_pages;
@@ -448,20 +453,22 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
     c->pitch = (r_w + 64 + 63) / 64 * 64;  // >= 64 zero bytes right of every row
     c->rows_alloc = r_h + 48;              // >= 48 zero rows below every page
     size_t bytes = c->n_pages * c->rows_alloc * c->pitch;
-    if (hipMalloc(&c->d_pages, bytes) != hipSuccess) {
-        c->d_pages = nullptr;
+    if (hipMalloc(&c->d_pages, bytes) != hipSuccess || hipMalloc(&c->d_pages_i8, bytes) != hipSuccess) {
+        free_dev(c->d_pages);
+        free_dev(c->d_pages_i8);
         c->n_pages = 0;
         return fail(c, FOCR_ERR_NOMEM, "focr_pages_alloc: hipMalloc failed");
     }
     c->pages_capacity = n_pages;
     FOCR_HIP(c, hipMemsetAsync(c->d_pages, 0, bytes, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(c->d_pages_i8, 0x80, bytes, c->stream));  // paper (0) as int8
     return FOCR_OK;
 }
 
 static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count, int invert) {
     size_t total = count * c->r_h * c->r_w;
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(256), 0, c->stream, d_src, c->d_pages, c->r_w, c->r_h, c->pitch,
+    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(256), 0, c->stream, d_src, c->d_pages, c->d_pages_i8, c->r_w, c->r_h, c->pitch,
                        c->rows_alloc, first, count, invert);
     FOCR_HIP(c, hipGetLastError());
     c->scanned = c->processed = false;

@@ -50,7 +50,7 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
 //     V = n*s2 - s^2 = n * norm_p^2                                  (full box; V > 0 <=> the reference's rnorm is finite)
 //     W = n_k^2*q2 - 2*n_k*s_k*q1 + D*s_k^2 = n_k^2 * dnorm^2        (q1, q2: sums over the dropped column, D its taps)
 // then L = kq*sqrt(V) - crk*sqrt(W) in f32 with kq rounded towards -inf and crk up (host: plane_params) — f32 errors stay
-// below 1 for |L| < 4e6 and are absorbed by the "- 2" of prefilter_cin — and the stored value is L / S rounded TOWARDS -INF
+// below 1 for |L| < 4e6 and are absorbed by a "- 2" — and the stored value is (L - 2) / S rounded TOWARDS -INF
 // to f16 (a lower threshold only admits more candidates), +inf where the reference never emits (x = 0, y = 0, window outside
 // the page, zero variance).  Round 2 stored the window norm (rounded towards zero) and multiplied by kappa in the scan
 // kernel, which raised the threshold for kappa < 0; a directed rounding of L itself has no sign cases.
@@ -117,10 +117,16 @@ __host__ __device__ inline int32_t threshold_negL(float Lf) {
     f = __builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f);
     return -(int32_t)f;
 }
-// C-in of one window from its plane value v (as f32; +inf = never): -(floor(S * v) - 2).  S * v is exact (S a power of two).
+// Plane value of a window that can emit: (L - 2) / S rounded towards -inf to f16 — the "- 2" that absorbs the f32 roundings
+// of L rides in the stored value, so the scan kernel's C-in costs it one instruction less per window and size class.
+__host__ __device__ inline uint16_t plane_value(const PlaneParams &p, float Lf) {
+    Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
+    return f16_down((Lf - 2.0f) * p.inv_S);
+}
+// C-in of one window from its plane value v (as f32; +inf = never): -floor(S * v).  S * v is exact (S a power of two);
+// +inf comes out as -1e9, an unreachable threshold (|G| < 2^24).  Five instructions: cvt, mul, floor, med3, cvt (negated).
 __host__ __device__ inline int prefilter_cin(float S, float v) {
-    float f = __builtin_floorf(S * v) - 2.0f;
-    f = __builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f);  // +inf -> an unreachable threshold (|G| < 2^24)
+    const float f = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(S * v), -1.0e9f), 1.0e9f);
     return -(int)f;
 }
 

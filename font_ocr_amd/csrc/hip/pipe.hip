@@ -155,12 +155,13 @@ int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
             focr_pipe_destroy(p);
             return rc;
         }
-        // several batches in flight: the persistent scan kernel takes three quarters of the CUs and leaves the rest to the other
-        // batches' small kernels (statistics, verify, sorts, process_hits) — a scan workgroup fills its CU completely, so they run
-        // nowhere else while a scan is on.  Measured at BASELINE configs[1], 3 batches in flight: 176 / 192 / 208 / 224 / 256 CUs
-        // -> 21.8 / 22.4 / 20.9 / 21.1 / 19.5 Gpx/s (profiles/r02_cu_sweep.log).
+        // several batches in flight: the persistent scan kernel takes seven eighths of the CUs and leaves the rest to the other
+        // batches' small kernels (statistics, row tail, ordering, process_hits) — a scan workgroup fills its CU completely, so
+        // they run nowhere else while a scan is on.  Measured at BASELINE configs[1], 3 batches in flight: round 3 (tail 0.77 ms of
+        // full-chip time per batch) 176 / 192 / 208 / 224 / 240 / 256 CUs -> 27.7 / 28.5-29.8 / 28.3-29.1 / 28.9-29.4 / 25.5 / 26.1 Gpx/s
+        // (gpurun_out/r3_g_*, r3_h_*, r3_j_*: flat from 192 to 224); round 2 (tail 1.3 ms) had a sharp optimum at 192.
         if (n_contexts > 1 && hipGetDeviceProperties(&prop, device) == hipSuccess)
-            focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 4));
+            focr_ctx_set_scan_cus(L->ctx, (unsigned)(prop.multiProcessorCount - prop.multiProcessorCount / 8));
         L->worker = std::thread(lane_main, L, p);
         p->lanes.push_back(L);
     }

@@ -68,9 +68,8 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
                 }
             const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;
             const float Wf = kw != sc.n_w ? (float)dropped_column_W(n_k, n - n_k, s - q1, q1, q2) : 0.f;
-            float Lf = threshold_f32(p, (float)V, Wf);
-            Lf = fminf(fmaxf(Lf, -1.0e9f), 1.0e9f);
-            const uint16_t plane = V != 0 ? f16_down(Lf * p.inv_S) : PLANE_NEVER;
+            const float Lf = threshold_f32(p, (float)V, Wf);
+            const uint16_t plane = V != 0 ? plane_value(p, Lf) : PLANE_NEVER;
             const int cin = prefilter_cin(p.S, f16_bits_to_f32(plane));
             const double norm_p = std::sqrt((double)V / (double)n);
             for (uint32_t i = 0; i < sc.n_templates; i++) {

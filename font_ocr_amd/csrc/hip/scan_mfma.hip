@@ -79,8 +79,7 @@ struct StatsOut {  // what a statistics launch writes for one size class
 template <int OUT>
 __device__ __forceinline__ void stats_store(const StatsOut &o, size_t idx, bool emit, float Lf) {
     if (OUT) {
-        Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-        reinterpret_cast<uint16_t *>(o.out)[idx] = emit ? f16_down(Lf * o.p.inv_S) : PLANE_NEVER;
+        reinterpret_cast<uint16_t *>(o.out)[idx] = emit ? plane_value(o.p, Lf) : PLANE_NEVER;
     } else {
         reinterpret_cast<int32_t *>(o.out)[idx] = emit ? threshold_negL(Lf) : -REJECT;
     }
@@ -637,6 +636,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx || su.ksteps > 4 || su.classes.size() > (size_t)MAX_PLANE_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY) continue;
             const uint32_t nv = (uint32_t)su.classes.size();
+            if ((size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane * 2 >= ((size_t)1 << 32)) continue;  // the plane kernel addresses a pass's planes with 32-bit offsets
             two[si] = 1;
             plane_off[si] = plane_vals;
             plane_vals += (size_t)(nv <= 1 ? 1 : nv <= 2 ? 2 : 4) * plane;  // the kernel is instantiated for 1 / 2 / 4 values

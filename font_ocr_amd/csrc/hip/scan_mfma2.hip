@@ -99,8 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
                     a = v4i{*reinterpret_cast<const int_u *>(q0), *reinterpret_cast<const int_u *>(q0 + pitch),
                             *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch), *reinterpret_cast<const int_u *>(q0 + 3 * (size_t)pitch)};
                 }
-                // u8 -> i8 (a - 128): the quantised templates sum to zero, so the bias cancels exactly
-                afrag[mt][ks] = a ^ (int)0x80808080;
+                afrag[mt][ks] = a;  // the page copy is already int8 (ink - 128, written at ingest; the templates sum to zero: the bias cancels exactly)
             }
         }
         take.request();  // the next item's ticket
@@ -243,6 +242,17 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
             if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) S_of_value[v] = P.S[sg];
     }
 
+    // byte offsets of the lane's rows inside an M-tile's fragment, relative to the wave-uniform base (layouts: mfma_common.h)
+    uint32_t lane_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        lane_off[j] = RPG == LAYOUT_W16 ? (uint32_t)r + (uint32_t)g * pitch
+                      : RPG == LAYOUT_W8 ? (uint32_t)r + (uint32_t)(2 * g + (j & 1)) * pitch
+                                         : (uint32_t)r + (uint32_t)(4 * g + j) * pitch;
+    uint32_t plane_off[NV];  // the lane's own window inside an M-tile's entries of plane v, in bytes (all planes of a pass span < 4 GiB: launch_scan_mfma)
+#pragma unroll
+    for (int v = 0; v < NV; v++) plane_off[v] = (uint32_t)r * 2 + (uint32_t)v * (uint32_t)(P.stride * 2);
+
     ItemTaker take;
     take.init(queue, n_items, lane);
     v4i afrag[MT][KSTEPS];
@@ -273,6 +283,16 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
             py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
             pp[mt] = (uint32_t)(e >> 32);
         }
+        // The lane offsets are made opaque here, once per item: left visible, "pages + lane offset" is loop-invariant and gets
+        // hoisted as a 64-bit vector pointer, and every load then pays a 64-bit vector add of its uniform part; opaque, the
+        // uniform part stays in scalar registers and the load takes "scalar base + 32-bit vector offset" directly.
+        uint32_t lo[4] = {lane_off[0], lane_off[1], lane_off[2], lane_off[3]}, po[NV];
+        asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            po[v] = plane_off[v];
+            asm volatile("" : "+v"(po[v]));
+        }
         float nrm[MT][NV];  // threshold-plane values of the lane's own window px + r, one per size class
 #ifdef FOCR_V2S_VARIANTS
         if (variant & 8) {
@@ -287,30 +307,33 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 #endif
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const uint16_t *np = P.planes + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt] + r;
+            const uint8_t *np = reinterpret_cast<const uint8_t *>(P.planes + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt]);  // wave-uniform
 #pragma unroll
-            for (int v = 0; v < NV; v++) nrm[mt][v] = f16_bits_to_f32(np[(size_t)v * P.stride]);  // L / S rounded towards -inf; +inf = never
+            for (int v = 0; v < NV; v++)  // (L - 2) / S rounded towards -inf; +inf = never
+                nrm[mt][v] = f16_bits_to_f32(*reinterpret_cast<const uint16_t *>(np + po[v]));
         }
-        // K-step-major issue order: the N-tile loop's first MFMAs need K-step 0 of all M-tiles
+        // K-step-major issue order: the N-tile loop's first MFMAs need K-step 0 of all M-tiles.  An address is a wave-uniform
+        // 64-bit base (page, row, M-tile, K-step: scalar arithmetic) plus a 32-bit lane offset that never changes (lane_off[],
+        // computed once per kernel) — no vector instruction per load; the pages are the int8 copy, so no v_xor either.
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ks++) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const uint8_t *base = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt] + r;
+                const uint8_t *ub = pages + ((size_t)pp[mt] * rows_alloc + py[mt]) * pitch + px[mt];  // wave-uniform
                 v4i a;
                 if (RPG == LAYOUT_W16) {
-                    a = *reinterpret_cast<const v4i_u *>(base + (size_t)(4 * ks + g) * pitch);
+                    a = *reinterpret_cast<const v4i_u *>(ub + (size_t)(4 * ks) * pitch + lo[0]);
                 } else if (RPG == LAYOUT_W8) {
-                    const uint8_t *p0 = base + (size_t)(2 * (4 * ks + g)) * pitch;
-                    const v2i lo = *reinterpret_cast<const v2i_u *>(p0), hi = *reinterpret_cast<const v2i_u *>(p0 + pitch);
-                    a = v4i{lo[0], lo[1], hi[0], hi[1]};
+                    const uint8_t *u0 = ub + (size_t)(8 * ks) * pitch;
+                    const v2i w0 = *reinterpret_cast<const v2i_u *>(u0 + lo[0]), w1 = *reinterpret_cast<const v2i_u *>(u0 + lo[1]);
+                    a = v4i{w0[0], w0[1], w1[0], w1[1]};
                 } else {
                     // LAYOUT_W12: K-step 3*(m/4) + c = dword column c of the rows of quad m = 4*(ks/3)+g (mfma_common.h)
-                    const uint8_t *q0 = base + (size_t)(4 * (4 * (ks / 3) + g)) * pitch + 4 * (ks % 3);
-                    a = v4i{*reinterpret_cast<const int_u *>(q0), *reinterpret_cast<const int_u *>(q0 + pitch),
-                            *reinterpret_cast<const int_u *>(q0 + 2 * (size_t)pitch), *reinterpret_cast<const int_u *>(q0 + 3 * (size_t)pitch)};
+                    const uint8_t *u0 = ub + (size_t)(16 * (ks / 3)) * pitch + 4 * (ks % 3);
+                    a = v4i{*reinterpret_cast<const int_u *>(u0 + lo[0]), *reinterpret_cast<const int_u *>(u0 + lo[1]),
+                            *reinterpret_cast<const int_u *>(u0 + lo[2]), *reinterpret_cast<const int_u *>(u0 + lo[3])};
                 }
-                afrag[mt][ks] = a ^ (int)0x80808080;  // u8 -> i8 (a - 128): the quantised templates sum to zero
+                afrag[mt][ks] = a;
             }
         }
 #ifdef FOCR_V2S_VARIANTS
@@ -323,13 +346,14 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         PROF2(1)
 #endif
         // C-in of the lane's own window per size class (prefilter_cin, mfma_common.h; a window the class never emits at holds
-        // +inf, which comes out as an unreachable threshold), -REJECT past the enumeration
+        // +inf, which comes out as an unreachable threshold).  M-tiles past the end of the enumeration repeat the last live one:
+        // they are dropped where candidates are emitted (rare path), not here
         int cin[MT][NV];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                cin[mt][v] = pv[mt] ? prefilter_cin(S_of_value[v], nrm[mt][v]) : -REJECT;
+                cin[mt][v] = prefilter_cin(S_of_value[v], nrm[mt][v]);
             }
         v4i bf[KSTEPS];
 #pragma unroll
@@ -381,6 +405,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
                     const v4i tg4 = reinterpret_cast<const v4i *>(tg_lds)[nt * 4 + g];
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
+                        if (!pv[mt]) continue;  // past the end of the enumeration (a repeat of the last live M-tile): wave-uniform
                         const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
                         if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
 #ifdef FOCR_V2S_VARIANTS
@@ -441,7 +466,7 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, un
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2s_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages_i8 + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, reinterpret_cast<const v4i *>(c->d_qbank + L.q_offset), n_tiles16, L.segs, L.Lpitch, L.Lrows, A3,
                        c->d_tglobal + L.tg_offset, c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1, (unsigned long long)c->ub_cand, L.queue, c->row_hist);
     c->launch_end();
@@ -491,7 +516,7 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     char name[64];
     snprintf(name, sizeof name, "scan_mfma2_kernel<%d,%d,%d,%d>", KSTEPS, RPG, MT, NW);
     c->launch_begin(name, L.n_templates | (L.super_index << 24), L.alg_macs, issued);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, c->d_pages_i8 + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch, (uint32_t)c->rows_alloc,
                        L.live_list, L.live_count, (uint32_t)c->sub_p0, qb, n_tiles16, L.segs, L.Lpitch, L.Lrows, c->d_tglobal + L.tg_offset,
                        c->fmt, c->d_cand, (unsigned long long *)c->d_counter + 1,
                        (unsigned long long)c->ub_cand, L.queue, c->row_hist);
