@@ -22,18 +22,28 @@ int fail(focr_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
-// tight luma8 pages -> pitched ink-high pages (image_to_u8, src/ncc.rs:887-892, on the device)
-__global__ void ingest_pages(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint8_t *__restrict__ dst_i8, size_t r_w, size_t r_h,
-                             size_t pitch, size_t rows_alloc, size_t first, size_t count, int invert) {
-    size_t total = count * r_h * r_w;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t p = i / (r_h * r_w), rem = i % (r_h * r_w);
-        size_t y = rem / r_w, x = rem % r_w;
-        uint8_t v = src[i];
-        v = invert ? (uint8_t)(255 - v) : v;
-        const size_t o = ((first + p) * rows_alloc + y) * pitch + x;
-        dst[o] = v;
-        dst_i8[o] = v ^ 0x80;  // ink - 128 as int8: the prefilter's operand (its templates sum to zero, so the bias cancels exactly)
+// tight luma8 pages -> pitched ink-high pages (image_to_u8, src/ncc.rs:887-892, on the device) + their int8 copy.
+// One workgroup of 64 threads per page row; 4 pixels per thread and step when the rows are dword-aligned, else bytes.
+__global__ __launch_bounds__(64) void ingest_pages(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint8_t *__restrict__ dst_i8, uint32_t r_w,
+                                                   uint32_t r_h, size_t pitch, size_t rows_alloc, size_t first, size_t n_rows, int invert, int dwords) {
+    const uint32_t flip = invert ? 0xffffffffu : 0u;
+    for (size_t row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const size_t p = row / r_h, y = row % r_h;
+        const uint8_t *s = src + row * r_w;
+        const size_t o = ((first + p) * rows_alloc + y) * pitch;
+        if (dwords) {  // r_w % 4 == 0 and src 4-byte aligned (pitch is a multiple of 64)
+            for (uint32_t x = threadIdx.x; x < r_w / 4; x += 64) {
+                const uint32_t v = reinterpret_cast<const uint32_t *>(s)[x] ^ flip;  // 255 - v per byte
+                reinterpret_cast<uint32_t *>(dst + o)[x] = v;
+                reinterpret_cast<uint32_t *>(dst_i8 + o)[x] = v ^ 0x80808080u;  // ink - 128 as int8: the prefilter's operand
+            }
+        } else {
+            for (uint32_t x = threadIdx.x; x < r_w; x += 64) {
+                const uint8_t v = (uint8_t)(s[x] ^ (uint8_t)flip);
+                dst[o + x] = v;
+                dst_i8[o + x] = v ^ 0x80;
+            }
+        }
     }
 }
 
@@ -466,10 +476,11 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
 }
 
 static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count, int invert) {
-    size_t total = count * c->r_h * c->r_w;
-    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(256), 0, c->stream, d_src, c->d_pages, c->d_pages_i8, c->r_w, c->r_h, c->pitch,
-                       c->rows_alloc, first, count, invert);
+    const size_t n_rows = count * c->r_h;
+    const unsigned blocks = (unsigned)std::min<size_t>(n_rows, (size_t)1 << 20);
+    const int dwords = c->r_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0;
+    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(64), 0, c->stream, d_src, c->d_pages, c->d_pages_i8, (uint32_t)c->r_w, (uint32_t)c->r_h, c->pitch,
+                       c->rows_alloc, first, n_rows, invert, dwords);
     FOCR_HIP(c, hipGetLastError());
     c->scanned = c->processed = false;
     c->sizes_pending = c->post_pending = false;  // results of the previous batch are gone with its pages

@@ -144,7 +144,16 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 //                 (batch redone through the legacy tail).
 constexpr uint32_t XBINS = 1024;
 template <int CAP, int WAVES, bool LIST>
-__global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+#ifdef FOCR_TAIL_SMALL
+#define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64, LIST ? 1 : 8)
+#define VERIFY_THREADS 256
+#define VERIFY_BOUNDS __launch_bounds__(256, 8)
+#else
+#define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64)
+#define VERIFY_THREADS 1024
+#define VERIFY_BOUNDS __launch_bounds__(1024)
+#endif
+__global__ ROW_SORT_BOUNDS void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
                                                               uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t seg_mask, uint32_t xs, uint32_t n_bins,
                                                               uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 bin starts, CAP placed sub-keys
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
 // operand (16 bytes per template row) is staged in LDS once per workgroup — when all of it fits 144 KiB (BASELINE
 // configs[1]: 380 templates, 91 KB); larger banks keep the global loads (LDS = false).
 template <bool LDS>
-__global__ __launch_bounds__(1024) void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
+__global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
                                                            const VerifyArgs va, uint32_t lds_rows, const RowHist rows, float *__restrict__ bsims,
                                                            uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
     extern __shared__ __attribute__((aligned(16))) v4i needle_lds[];
@@ -425,13 +434,13 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         for (const TemplateConst &tc : c->h_tconst) all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
         const bool in_lds = all_rows * 16 <= ((size_t)144 << 10);
         const size_t lds = in_lds ? all_rows * 16 : 0;
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + 1023) / 1024, (size_t)cus));
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
         if (in_lds) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(1024), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
+            hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
                                (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
         } else {
-            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * 4), dim3(1024), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
+            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * 4), dim3(VERIFY_THREADS), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
                                va, 0u, c->row_hist, bsims, bflags, hits);
         }
         FOCR_HIP(c, hipGetLastError());
