@@ -48,7 +48,8 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
 // dnorm(w) * rho_t,  dnorm = |a_drop - m|_2,  rho_t = |beta_drop|_2 <= rho_max.  Hence sim > thr  =>  G > L: no false
 // negatives, for either sign of kappa.  Everything up to the square roots is exact integer arithmetic:
 //     V = n*s2 - s^2 = n * norm_p^2                                  (full box; V > 0 <=> the reference's rnorm is finite)
-//     W = n_k^2*q2 - 2*n_k*s_k*q1 + D*s_k^2 = n_k^2 * dnorm^2        (q1, q2: sums over the dropped column, D its taps)
+//     W = n_k^2*q2 - 2*n_k*s_k*q1 + D*s_k^2 = n_k^2 * dnorm^2        (q1, q2: sums over the dropped column, D its taps;
+//                                                                      evaluated as an f32 upper bound: dropped_column_W_upper)
 // then L = kq*sqrt(V) - crk*sqrt(W) in f32 with kq rounded towards -inf and crk up (host: plane_params) — f32 errors stay
 // below 1 for |L| < 4e6 and are absorbed by a "- 2" — and the stored value is (L - 2) / S rounded TOWARDS -INF
 // to f16 (a lower threshold only admits more candidates), +inf where the reference never emits (x = 0, y = 0, window outside
@@ -107,9 +108,15 @@ __host__ __device__ inline float sqrt_fast(float x) {
 __host__ __device__ inline float threshold_f32(const PlaneParams &p, float Vf, float Wf) {
     return __builtin_fmaf(-p.crk, sqrt_fast(Wf), p.kq * sqrt_fast(Vf));
 }
-// W = n_k^2 * dnorm^2, exact (fits 64 bits: n_k <= 512, sums of <= 32 taps)
-__host__ __device__ inline uint64_t dropped_column_W(uint32_t n_k, uint32_t D, uint32_t s_k, uint32_t q1, uint32_t q2) {
-    return (uint64_t)n_k * n_k * q2 + (uint64_t)D * s_k * s_k - 2ull * n_k * (uint64_t)s_k * q1;
+// An UPPER bound of W = n_k^2 * dnorm^2 = n_k^2 q2 + D s_k^2 - 2 n_k s_k q1 in f32 (the exact value needs 64-bit integer
+// multiplies, quarter-rate instructions on the vector unit; this is five full-rate ones).  Every factor is an integer below
+// 2^24, so each of the three products carries at most two roundings and the sum three more: |error| < 7 * 2^-24 * (t1 + t2 + t3)
+// — the 2^-21 * (t1 + t2 + t3) added on top makes the result >= W (>= 0) always.  An over-estimated dnorm only lowers the
+// threshold: by sqrt(2^-21 * 3 n_k^2 q2) / n_k * c * rho, a few units of L on thresholds of 10^5.
+__host__ __device__ inline float dropped_column_W_upper(uint32_t n_k, uint32_t D, uint32_t s_k, uint32_t q1, uint32_t q2) {
+    const float sk = (float)s_k;
+    const float t1 = (float)(n_k * n_k) * (float)q2, t3 = (float)D * (sk * sk), t2 = (float)(2 * n_k) * (sk * (float)q1);
+    return __builtin_fmaf(t1 + t2 + t3, 0x1p-21f, (t1 + t3) - t2);
 }
 // legacy int32 table entry (scan_mfma2_kernel): -(floor(L) - 2)
 __host__ __device__ inline int32_t threshold_negL(float Lf) {

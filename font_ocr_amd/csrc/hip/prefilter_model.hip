@@ -67,7 +67,7 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
                     if (x >= kw) q1 += v, q2 += v * v;
                 }
             const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;
-            const float Wf = kw != sc.n_w ? (float)dropped_column_W(n_k, n - n_k, s - q1, q1, q2) : 0.f;
+            const float Wf = kw != sc.n_w ? dropped_column_W_upper(n_k, n - n_k, s - q1, q1, q2) : 0.f;
             const float Lf = threshold_f32(p, (float)V, Wf);
             const uint16_t plane = V != 0 ? plane_value(p, Lf) : PLANE_NEVER;
             const int cin = prefilter_cin(p.S, f16_bits_to_f32(plane));

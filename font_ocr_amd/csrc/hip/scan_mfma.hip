@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
         if (DROP) {
             const uint32_t b = lastc[(size_t)(r0 + j) * (SLDW * 4)];
             q1 += b;
-            q2 += b * b;
+            q2 += __umul24(b, b);
         }
     }
     const uint32_t n = n_w * n_h, n_k = (n_w - 1) * n_h;
@@ -167,16 +167,17 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     // the reference prunes it too, src/ncc.rs:280-301).  Row y of the image is tile row y - 1.
     const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
     const size_t live_i = ((size_t)page * n_rows + ya) * mtx + (x >> 4);  // entry of image row ya + 1
+    size_t idx = ((size_t)page * Lrows + ya) * Lpitch + x;  // the window's entry in the planes; one row further per step
 #pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
+    for (uint32_t k = 0; k < PER; k++, idx += Lpitch) {
         const uint32_t y = ya + k;
         if (y < Lrows) {
             // V = n*s2 - s*s, exact; V > 0 <=> the reference's rnorm is finite.  SMALLN (n <= 256): both products
             // fit 32 bits (n*s2 <= n^2 * 255^2 < 2^32, s <= 255 n < 2^16).
             bool nz;
             float Vf;
-            if (SMALLN) {
-                const uint32_t V = n * s2 - s * s;
+            if (SMALLN) {  // n <= 256: n, s, s2 < 2^24 -> full-rate 24-bit multiplies (a 32-bit v_mul_lo is a quarter-rate instruction)
+                const uint32_t V = __umul24(n, s2) - __umul24(s, s);
                 nz = V != 0;
                 Vf = (float)V;
             } else {
@@ -186,16 +187,15 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             }
             const bool y_ok = y >= 1 && y + n_h <= r_h;
             const uint32_t s_k = s - q1, s2_k = s2 - q2;  // the kept box (DROP)
-            const float Wf = DROP ? (float)dropped_column_W(n_k, n_h, s_k, q1, q2) : 0.f;
+            const float Wf = DROP ? dropped_column_W_upper(n_k, n_h, s_k, q1, q2) : 0.f;
             const bool emit = x_ok && y_ok && nz;
             bool any = emit;
-            const size_t idx = ((size_t)page * Lrows + y) * Lpitch + x;
             stats_store<OUT>(A, idx, emit, threshold_f32(A.p, Vf, Wf));
             if (PAIR) {  // the kept box as a size class of its own: (n_w - 1) x n_h, nothing dropped
                 bool nzk;
                 float Vkf;
                 if (SMALLN) {
-                    const uint32_t Vk = n_k * s2_k - s_k * s_k;
+                    const uint32_t Vk = __umul24(n_k, s2_k) - __umul24(s_k, s_k);
                     nzk = Vk != 0;
                     Vkf = (float)Vk;
                 } else {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             if (DROP) {
                 const uint32_t bi = lastc[(size_t)(r0 + k + n_h) * (SLDW * 4)], bo = lastc[(size_t)(r0 + k) * (SLDW * 4)];
                 q1 += bi - bo;
-                q2 += bi * bi - bo * bo;
+                q2 += __umul24(bi, bi) - __umul24(bo, bo);
             }
         }
     }
