@@ -148,6 +148,7 @@ struct focr_ctx {
     uint32_t *d_needle_off = nullptr;
     uint8_t *d_needles16 = nullptr;             // class-ordered, n_h rows of 16 bytes each (verify operand)
     uint32_t *d_needle16_row = nullptr;         // class-ordered first row index into d_needles16
+    void *d_vmeta = nullptr;                    // VerifyMeta by GLOBAL template index (mfma_common.h): what the verify needs about a template, 32 B
     uint32_t *d_t_w = nullptr, *d_t_h = nullptr, *d_t_letter = nullptr;  // by global template index
 
     // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded

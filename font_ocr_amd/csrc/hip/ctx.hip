@@ -91,6 +91,7 @@ static void free_bank(focr_ctx *c) {
     free_dev(c->d_needle_off);
     free_dev(c->d_needles16);
     free_dev(c->d_needle16_row);
+    free_dev(c->d_vmeta);
     free_dev(c->d_t_w);
     free_dev(c->d_t_h);
     free_dev(c->d_t_letter);

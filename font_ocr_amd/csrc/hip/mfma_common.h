@@ -266,6 +266,13 @@ struct MfmaLaunch {
 
 // ---- exact verify of one candidate: the reference arithmetic, operation for operation (common.h) ----
 typedef v4i v4i_b1 __attribute__((aligned(1)));  // byte-aligned 16-byte view (gfx950 global loads take any alignment)
+// Everything the verify needs to know about a template, by GLOBAL template index, 32 bytes: one LDS read instead of three
+// dependent gathers from global memory (order_of -> TemplateConst -> needle16_row).
+struct VerifyMeta {
+    double s_n, n_recip, rnorm_n;
+    uint16_t n_w, n_h;
+    uint32_t row0;  // first row of the template in needles16
+};
 struct VerifyArgs {
     const uint8_t *pages;
     uint32_t pitch, rows_alloc;
@@ -275,6 +282,7 @@ struct VerifyArgs {
     const v4i *needles16;            // every template as n_h rows of 16 bytes (zero padded; two halves per row above 16 px)
     const uint32_t *needle16_row;    // class-ordered first row
     double thr_d;
+    const struct VerifyMeta *vmeta;           // by global template index (the row tail's verify stages it in LDS)
     uint32_t n_templates, n_pages, r_w, r_h;  // bounds of a well-formed key
     unsigned long long *flags_word;           // d_res[4]: bit 2 = a key outside those bounds was met (internal error, never a fault)
 };
@@ -319,6 +327,46 @@ __device__ __forceinline__ bool verify_candidate_t(uint64_t key, const VerifyArg
         }
     }
     const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)(c.n_w * c.n_h));
+    const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
+    *sim_out = (float)sim;
+    return ncc_emits(sim, va.thr_d);
+}
+// The row tail's form: template metadata from `meta` (LDS copy of va.vmeta, by global template index), template rows from
+// LDS (LDS = true) or global memory.  Same arithmetic, same order of operations.
+template <bool LDS>
+__device__ __forceinline__ bool verify_candidate_meta(uint64_t key, const VerifyArgs &va, const v4i *lds, const VerifyMeta *meta, float *sim_out) {
+    const uint32_t page = va.fmt.page(key), t = va.fmt.t(key), x = va.fmt.x(key), y = va.fmt.y(key);
+    if (t >= va.n_templates || page >= va.n_pages || x >= va.r_w || y >= va.r_h) {  // cannot happen; would otherwise be a wild read
+        atomicOr(va.flags_word, 4ull);
+        *sim_out = 0.f;
+        return false;
+    }
+    const VerifyMeta c = meta[t];
+    const uint32_t halves = c.n_w > 16 ? 2 : 1;
+    const v4i *nd = va.needles16 + c.row0;
+    const uint8_t *pg = va.pages + ((size_t)page * va.rows_alloc + y) * va.pitch + x;  // rows have >= 64 readable bytes past r_w
+    uint32_t acc = 0, s_p = 0, s2_p = 0;
+    for (uint32_t hf = 0; hf < halves; hf++) {
+        const uint32_t w_here = min((uint32_t)c.n_w - 16 * hf, 16u);
+        v4i keep;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            keep[k] = w_here >= (uint32_t)(4 * k + 4) ? -1 : (w_here <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (w_here - 4 * k))) - 1u));
+#pragma unroll 8
+        for (uint32_t j = 0; j < c.n_h; j++) {
+            const v4i a = *reinterpret_cast<const v4i_b1 *>(pg + (size_t)j * va.pitch + 16 * hf) & keep;
+            v4i b;
+            if (LDS) b = lds[c.row0 + j * halves + hf];
+            else b = nd[j * halves + hf];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
+                s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
+                s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
+            }
+        }
+    }
+    const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)((uint32_t)c.n_w * c.n_h));
     const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
     *sim_out = (float)sim;
     return ncc_emits(sim, va.thr_d);

@@ -261,11 +261,14 @@ template <bool LDS>
 __global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
                                                            const VerifyArgs va, uint32_t lds_rows, const RowHist rows, float *__restrict__ bsims,
                                                            uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
-    extern __shared__ __attribute__((aligned(16))) v4i needle_lds[];
-    if (LDS) {
+    // LDS: [template records: n_templates x 32 B][template rows, 16 B each, if LDS]
+    extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
+    v4i *needle_lds = verify_lds + 2 * va.n_templates;
+    for (uint32_t i = threadIdx.x; i < 2 * va.n_templates; i += blockDim.x) verify_lds[i] = reinterpret_cast<const v4i *>(va.vmeta)[i];
+    if (LDS)
         for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
-        __syncthreads();
-    }
+    __syncthreads();
     const unsigned long long n = min((unsigned long long)*total_p, cap);
     const int lane = threadIdx.x & 63;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -274,7 +277,7 @@ __global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bu
         const bool valid = i < n;
         const uint64_t key = valid ? bucket[i] : 0;
         float sim = 0.f;
-        const bool emit = valid && verify_candidate_t<LDS>(key, va, needle_lds, &sim);
+        const bool emit = valid && verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim);
         if (valid) {
             bsims[i] = sim;
             bflags[i] = emit ? 1 : 0;
@@ -348,7 +351,8 @@ bool rows_applicable(const focr_ctx *c) {
     if (!c->rows_enabled) return false;
     for (const SizeClass &sc : c->classes)
         if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per bucket
-    return row_buckets(c) <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32;
+    static_assert(sizeof(VerifyMeta) == 32, "VerifyMeta is staged in LDS as two 16-byte words per template");
+    return row_buckets(c) <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32 && c->n_templates <= 4096;  // 4096 x 32 B of template records in the verify's LDS
 }
 
 // before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
@@ -432,15 +436,17 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         // the verify operand in LDS if all of it fits
         size_t all_rows = 0;
         for (const TemplateConst &tc : c->h_tconst) all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
-        const bool in_lds = all_rows * 16 <= ((size_t)144 << 10);
-        const size_t lds = in_lds ? all_rows * 16 : 0;
+        const size_t meta_bytes = c->n_templates * sizeof(VerifyMeta);  // <= 4096 templates here: 128 KiB at most
+        const bool in_lds = meta_bytes + all_rows * 16 <= ((size_t)144 << 10);
+        const size_t lds = meta_bytes + (in_lds ? all_rows * 16 : 0);
         const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
         if (in_lds) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
                                (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
         } else {
-            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * 4), dim3(VERIFY_THREADS), 0, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * (meta_bytes > ((size_t)64 << 10) ? 1 : 2)), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
                                va, 0u, c->row_hist, bsims, bflags, hits);
         }
         FOCR_HIP(c, hipGetLastError());

@@ -460,6 +460,15 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
     }
     FOCR_HIP(c, hipMalloc((void **)&c->d_needles16, n16.size() ? n16.size() : 16));
     FOCR_HIP(c, hipMemcpy(c->d_needles16, n16.data(), n16.size(), hipMemcpyHostToDevice));
+    {  // the verify's per-template record, by global template index
+        std::vector<VerifyMeta> vm(c->n_templates);
+        for (size_t ci = 0; ci < c->h_tconst.size(); ci++) {
+            const TemplateConst &tc = c->h_tconst[ci];
+            vm[tc.index] = VerifyMeta{tc.s_n, tc.n_recip, tc.rnorm_n, (uint16_t)tc.n_w, (uint16_t)tc.n_h, n16_row[ci]};
+        }
+        FOCR_HIP(c, hipMalloc(&c->d_vmeta, vm.size() * sizeof(VerifyMeta)));
+        FOCR_HIP(c, hipMemcpy(c->d_vmeta, vm.data(), vm.size() * sizeof(VerifyMeta), hipMemcpyHostToDevice));
+    }
     FOCR_HIP(c, hipMalloc((void **)&c->d_needle16_row, n16_row.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_needle16_row, n16_row.data(), n16_row.size() * 4, hipMemcpyHostToDevice));
     FOCR_HIP(c, hipMalloc((void **)&c->d_order_of, order_of.size() * 4));
@@ -529,7 +538,8 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
 
 VerifyArgs verify_args(const focr_ctx *c, double thr_d) {
     return VerifyArgs{c->d_pages, (uint32_t)c->pitch, (uint32_t)c->rows_alloc, c->fmt, c->d_order_of, c->d_tconst,
-                      reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, (uint32_t)c->n_templates, (uint32_t)c->n_pages,
+                      reinterpret_cast<const v4i *>(c->d_needles16), c->d_needle16_row, thr_d, reinterpret_cast<const VerifyMeta *>(c->d_vmeta),
+                      (uint32_t)c->n_templates, (uint32_t)c->n_pages,
                       (uint32_t)c->r_w, (uint32_t)c->r_h, (unsigned long long *)(c->d_res + 4)};
 }
 
