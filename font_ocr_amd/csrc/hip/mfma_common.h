@@ -352,17 +352,27 @@ __device__ __forceinline__ bool verify_candidate_meta(uint64_t key, const Verify
 #pragma unroll
         for (int k = 0; k < 4; k++)
             keep[k] = w_here >= (uint32_t)(4 * k + 4) ? -1 : (w_here <= (uint32_t)(4 * k) ? 0 : (int)((1u << (8 * (w_here - 4 * k))) - 1u));
-#pragma unroll 8
-        for (uint32_t j = 0; j < c.n_h; j++) {
-            const v4i a = *reinterpret_cast<const v4i_b1 *>(pg + (size_t)j * va.pitch + 16 * hf) & keep;
-            v4i b;
-            if (LDS) b = lds[c.row0 + j * halves + hf];
-            else b = nd[j * halves + hf];
+        // 16 page rows in flight at once (the kernel waits on memory four fifths of its time: one round trip per 16 rows, not
+        // two); rows past n_h are read — every page has 48 readable rows below it — but not accumulated
+        for (uint32_t j0 = 0; j0 < c.n_h; j0 += 16) {
+            v4i a[16];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                acc = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b[k], acc, false);     // src/ncc.cpp:316-321
-                s_p = __builtin_amdgcn_udot4((uint32_t)a[k], 0x01010101u, s_p, false);        // patch_sum, src/ncc.rs:307
-                s2_p = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)a[k], s2_p, false);   // sum of squares, src/ncc.rs:308
+            for (int jj = 0; jj < 16; jj++) a[jj] = *reinterpret_cast<const v4i_b1 *>(pg + (size_t)(j0 + jj) * va.pitch + 16 * hf);
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                const uint32_t j = j0 + jj;
+                if (j < c.n_h) {
+                    const v4i aw = a[jj] & keep;
+                    v4i b;
+                    if (LDS) b = lds[c.row0 + j * halves + hf];
+                    else b = nd[j * halves + hf];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        acc = __builtin_amdgcn_udot4((uint32_t)aw[k], (uint32_t)b[k], acc, false);    // src/ncc.cpp:316-321
+                        s_p = __builtin_amdgcn_udot4((uint32_t)aw[k], 0x01010101u, s_p, false);       // patch_sum, src/ncc.rs:307
+                        s2_p = __builtin_amdgcn_udot4((uint32_t)aw[k], (uint32_t)aw[k], s2_p, false);  // sum of squares, src/ncc.rs:308
+                    }
+                }
             }
         }
     }

@@ -272,10 +272,13 @@ __global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bu
     const unsigned long long n = min((unsigned long long)*total_p, cap);
     const int lane = threadIdx.x & 63;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {  // wave-uniform trip count
+    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    uint64_t key_next = first + lane < n ? bucket[first + lane] : 0;  // the next step's key is loaded a step ahead
+    for (unsigned long long i0 = first; i0 < n; i0 += stride) {  // wave-uniform trip count
         const unsigned long long i = i0 + lane;
         const bool valid = i < n;
-        const uint64_t key = valid ? bucket[i] : 0;
+        const uint64_t key = key_next;
+        if (i + stride < n) key_next = bucket[i + stride];
         float sim = 0.f;
         const bool emit = valid && verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim);
         if (valid) {
