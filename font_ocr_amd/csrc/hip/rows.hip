@@ -3,23 +3,27 @@
 // The prefilter leaves an unordered list of candidate keys (page, y, x, t).  The reference's order (process_hits order:
 // page, y, x, template; src/ncc.rs:741-752) used to be restored by a 5-pass radix sort of all candidates, followed by the
 // exact verify, a flag scan and a compaction (12 launches, ~0.5 ms alone on the chip at BASELINE configs[1]).  But a
-// candidate's (page, y) is one of only sub_np * r_h page rows (92 160 at configs[1], ~50 candidates each), so:
+// candidate's (page, y) is one of only sub_np * r_h page rows (92 160 at configs[1], ~50 candidates each), so candidates are
+// BUCKETED by page row — by a segment of 2^k pixels of a page row where rows are wide and banks large (row_segments below;
+// "row" in the names of this file means such a bucket) — and everything after that is per bucket:
 //
-//   scan kernels      every flushed candidate also counts towards its page row            (flush_wave_candidates, RowHist)
-//   row_prefix        exclusive prefix of the row counts -> row_base, the largest row        1 workgroup
-//   row_scatter       candidate -> row_base[row] + (next free slot of the row)               order inside a row: arbitrary
-//   row_sort<CAP>     one WAVE per row, wave-private LDS: counting sort by x, rank inside the x-bin by t — in place
-//   verify_flat       the reference arithmetic on every candidate (verify_candidate, mfma_common.h), one thread each: the
-//                     row-ordered list is dense, neighbouring lanes read the same page lines
-//                     (it also counts the hits of every row)
-//   row_prefix        exclusive prefix of the rows' hit counts -> the dense position of every row's hits, the hit total
-//   row_compact       one wave per row: the survivors, order kept, to dense (key, similarity) arrays in (page, y, x, t) order
-//                     — what order.hip takes over
+//   scan kernels      every flushed candidate also counts towards its bucket               (flush_wave_candidates, RowHist)
+//   row_prefix        exclusive prefix of the bucket counts -> base, the largest bucket     1 workgroup
+//   row_scatter       candidate -> base[bucket] + (next free slot of the bucket)            order inside a bucket: arbitrary
+//   row_sort          one WAVE per bucket: <= 64 keys ranked in registers by lane-to-lane comparison; else the sub-keys (x, t)
+//                     in registers, counting sort by x in wave-private LDS, rank inside the x-bin by t — back in place.
+//                     Buckets above 1024 go onto a list and through a second launch (capacity 4096, one wave per workgroup)
+//   verify_flat       the reference arithmetic on every candidate (verify_candidate_meta, mfma_common.h), one thread each:
+//                     the bucket-ordered list is dense, neighbouring lanes read the same page lines; template rows and
+//                     records come from LDS; it also counts the hits of every bucket
+//   row_prefix        exclusive prefix of the buckets' hit counts -> the dense position of every bucket's hits, the hit total
+//   row_compact       one wave per bucket: the survivors, order kept, to dense (key, similarity) arrays in (page, y, x, t)
+//                     order — what order.hip takes over
 //
-// Seven small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A row with more candidates than the
-// instantiated capacity (the host picks 256 / 1024 / 4096 from the largest row: exact mode knows it, estimated mode takes the
-// previous scan's) sets the overflow bit and the batch is redone; rows beyond 4096 candidates (very low thresholds) and
-// banks with tall classes take the legacy tail (scan_mfma.hip: radix sort + verify_kernel + compaction).
+// Seven small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A bucket above 4096 candidates (very
+// low thresholds), banks with templates taller than 32 px or more than 4096 templates: the legacy tail (scan_mfma.hip: radix
+// sort + verify_kernel + compaction).  Exact mode knows the largest bucket before it chooses; estimated mode goes by the
+// previous scan's, and a bucket that turns out too large sets the overflow bit: the batch is redone with exact sizes.
 #include "mfma_common.h"
 
 namespace focr {
