@@ -233,10 +233,18 @@ __global__ __launch_bounds__(256) void compact_live_tiles(const uint8_t *__restr
     __shared__ uint32_t block_base;
     const uint32_t first = (blockIdx.x * 256 + threadIdx.x) * CLT_PER_THREAD;
     uint32_t bits = 0;
+    if (first + CLT_PER_THREAD <= n_tiles) {  // the thread's 16 marks in one (byte-aligned) 16-byte load
+        typedef unsigned int clt_v4 __attribute__((ext_vector_type(4), aligned(1)));
+        const clt_v4 m = *reinterpret_cast<const clt_v4 *>(live + first);
 #pragma unroll
-    for (uint32_t k = 0; k < CLT_PER_THREAD; k++) {
-        const uint32_t i = first + k;
-        if (i < n_tiles && (live[i] || !skip_blank)) bits |= 1u << k;
+        for (uint32_t k = 0; k < CLT_PER_THREAD; k++)
+            if (((m[k / 4] >> (8 * (k % 4))) & 0xffu) || !skip_blank) bits |= 1u << k;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < CLT_PER_THREAD; k++) {
+            const uint32_t i = first + k;
+            if (i < n_tiles && (live[i] || !skip_blank)) bits |= 1u << k;
+        }
     }
     const uint32_t cnt = (uint32_t)__builtin_popcount(bits);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
