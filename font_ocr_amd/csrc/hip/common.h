@@ -31,6 +31,7 @@ struct SizeClass {
     uint32_t n_tiles16;       // ceil(n_templates / 16)
     uint32_t q_offset;        // byte offset of the class's quantised templates in d_qbank
     uint32_t tg_offset;       // entry offset of the class's template ids in d_tglobal (16 per N-tile, ~0 = padding/dead)
+    uint32_t n_live;          // templates that can emit: they take the class's first n_live slots (dead ones and padding follow)
 };
 
 // Classes whose A fragments are identical (same K layout, same number of K-steps) are scanned in one kernel
@@ -115,6 +116,7 @@ struct focr_ctx {
     std::vector<size_t> direct_bank_off;        // dword offset per class
     int8_t *d_qbank = nullptr;                  // quantised i8 templates for the MFMA prefilter (per-lane B layout)
     bool column_drop = true;                    // bound the last column of 9- / 13-wide classes instead of multiplying it (takes effect at the next bank upload)
+    std::vector<uint32_t> mfma_slot;            // per class-ordered template: its slot inside its class's N-tiles (tile = slot / 16)
     // ---- result sizes (ctx.hip: finish_results) ----
     // Every phase after the scan kernel takes its element count from device memory; the host only supplies upper bounds for
     // grids and buffers.  Exact mode reads the counts between the phases (as round 1 did); estimated mode (same bank,

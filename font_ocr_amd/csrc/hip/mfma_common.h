@@ -394,6 +394,7 @@ struct PlaneArgs {
     float S[MAX_SEGS];             // per segment of the launch: the unit of its class's plane
     uint32_t seg_value[MAX_SEGS];  // per segment: the plane (value) of its class
     uint32_t seg_full[MAX_SEGS];   // per segment: 0 if the class's templates are all zero in the last K-step (LAYOUT_W12, kept width <= 8)
+    uint32_t seg_dead_from[MAX_SEGS];  // per segment: first N-tile (chunk-local) that holds dead / padding slots — a class's live templates come first
 };
 
 // scan_mfma.hip (host)

@@ -44,12 +44,13 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
         const uint32_t ksteps = sc.k_groups / 4;
         for (uint32_t i = 0; i < sc.n_templates; i++) {
             std::vector<int> &q = bq[sc.first + i];
+            const uint32_t slot = c->mfma_slot[sc.first + i];
             q.assign((size_t)sc.keep_w * sc.n_h, 0);
             for (uint32_t j = 0; j < sc.n_h; j++)
                 for (uint32_t x = 0; x < sc.keep_w; x++) {
                     uint32_t ks, g, byte;
                     kgroup_of(sc.layout, j, x, &ks, &g, &byte);
-                    q[j * sc.keep_w + x] = qbank[sc.q_offset + ((size_t)((i / 16) * ksteps + ks) * 64 + g * 16 + i % 16) * 16 + byte];
+                    q[j * sc.keep_w + x] = qbank[sc.q_offset + ((size_t)((slot / 16) * ksteps + ks) * 64 + g * 16 + slot % 16) * 16 + byte];
                 }
         }
     }
@@ -77,7 +78,7 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
                 const size_t o = wi * n_templates + tc.index;
                 sim[o] = NAN;
                 d[o] = INT64_MIN;  // dead templates (constant needles) never reach the candidate list
-                if (tglobal[sc.tg_offset + i] == 0xffffffffu) continue;
+                if (tglobal[sc.tg_offset + c->mfma_slot[sc.first + i]] == 0xffffffffu) continue;
                 long G = 0;
                 for (uint32_t j = 0; j < sc.n_h; j++)
                     for (uint32_t x = 0; x < kw; x++) G += (long)((int)a[j * frame_w + x] - 128) * bq[sc.first + i][j * kw + x];

@@ -344,6 +344,22 @@ void layout_supers(focr_ctx *c) {
     }
 }
 
+// Which slot of its class's N-tiles each template takes: the caller's order, except that templates that never emit (constant
+// needles: the space glyph) go last, next to the padding — only a class's last tiles hold dead slots then, and the scan kernel
+// looks at slot ids in those tiles alone (scan_mfma2.hip, the candidate path).  The candidate KEYS carry the caller's template
+// index (tglobal), so nothing outside the scan kernel sees the order.
+// (Measured and dropped: grouping look-alike templates into the same tile, greedy by correlation — the four sub-pixel shifts of
+// a glyph then share a tile, yet BASELINE configs[1] visits 1.31 M N-tiles per batch either way: DESIGN.md, dead ends.)
+static std::vector<uint32_t> live_first_slots(const std::vector<std::vector<double>> &bp) {
+    std::vector<uint32_t> slot(bp.size(), 0);
+    uint32_t next = 0;
+    for (size_t i = 0; i < bp.size(); i++)
+        if (!bp[i].empty()) slot[i] = next++;
+    for (size_t i = 0; i < bp.size(); i++)
+        if (bp[i].empty()) slot[i] = next++;
+    return slot;
+}
+
 // Quantise the bank (header comment; column drop: mfma_common.h).  `dense` holds the class-ordered dense needles.  Host only:
 // fills the per-lane MFMA operand image of every class, the class-ordered template ids (~0 = dead / padding) and
 // c->mfma_c_scale / mfma_e_max / mfma_rho_max.
@@ -357,12 +373,14 @@ int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank,
     qbank.assign(q_bytes, 0);
     tglobal.assign(tg_entries, 0xffffffffu);
     order_of.assign(c->n_templates, 0);
+    c->mfma_slot.assign(c->h_tconst.size(), 0);
     c->mfma_c_scale.clear();
     c->mfma_e_max.clear();
     c->mfma_rho_max.clear();
     for (size_t k = 0; k < c->classes.size(); k++) {
         SizeClass &sc = c->classes[k];
         const uint32_t n = sc.n_w * sc.n_h, ksteps = sc.k_groups / 4, kw = sc.keep_w, n_k = kw * sc.n_h;
+        sc.n_live = 0;
         if (sc.tall) {
             for (uint32_t i = 0; i < sc.n_templates; i++) order_of[c->h_tconst[sc.first + i].index] = sc.first + i;
             c->mfma_c_scale.push_back(1.0);
@@ -385,7 +403,6 @@ int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank,
             const double mean = s / n, n2 = s2 - s * s / n;
             if (!(n2 > 0.0) || !std::isfinite(tc.rnorm_n)) continue;  // constant needle: rnorm_n = inf, never emits
             const double norm_n = std::sqrt(n2);
-            tglobal[sc.tg_offset + i] = tc.index;
             double sigma = 0, rho2 = 0;
             for (uint32_t j = 0; j < sc.n_h; j++)
                 for (uint32_t x = kw; x < sc.n_w; x++) {
@@ -401,6 +418,13 @@ int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank,
                     bp[i][j * kw + x] = b;
                     max_ratio = std::max(max_ratio, std::fabs(b));
                 }
+        }
+        const std::vector<uint32_t> slot = live_first_slots(bp);
+        for (uint32_t i = 0; i < sc.n_templates; i++) {
+            c->mfma_slot[sc.first + i] = slot[i];
+            if (bp[i].empty()) continue;
+            tglobal[sc.tg_offset + slot[i]] = c->h_tconst[sc.first + i].index;
+            sc.n_live++;
         }
         const double c_scale = max_ratio > 0 ? 126.0 / max_ratio : 1.0;
         double e_max = 0.0;
@@ -432,7 +456,7 @@ int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank,
             if (check != 0) return fail(c, FOCR_ERR_INVALID, "mfma bank: quantised template does not sum to zero");
             e_max = std::max(e_max, std::sqrt(e2));
             // scatter into the per-lane MFMA B layout: [n-tile][k-step][g][n][16 bytes]
-            const uint32_t nt = i / 16, nn = i % 16;
+            const uint32_t nt = slot[i] / 16, nn = slot[i] % 16;
             for (uint32_t j = 0; j < sc.n_h; j++)
                 for (uint32_t x = 0; x < kw; x++) {
                     uint32_t ks, g, byte;
@@ -755,6 +779,10 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                     A3.S[L.segs.n] = plane_params(c, su.classes[i], thr_d).S;  // the unit of the class's plane
                     A3.seg_value[L.segs.n] = (uint32_t)i;
                     A3.seg_full[L.segs.n] = (su.layout == LAYOUT_W12 && sc.keep_w <= 8) ? 0u : 1u;  // mfma_common.h: K layouts
+                    {  // tiles of the class from n_live / 16 on hold dead / padding slots; chunk-local numbering
+                        const uint32_t dead = cb + sc.n_live / 16;
+                        A3.seg_dead_from[L.segs.n] = dead > t0 ? dead - t0 : 0u;
+                    }
                     MfmaSeg &sg = L.segs.s[L.segs.n++];
                     sg.negL = c->d_L + su.classes[i] * L_per_class;
                     sg.tile_end = e - t0;

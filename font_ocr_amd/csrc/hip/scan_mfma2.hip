@@ -199,6 +199,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 // experiment builds only: timing of the kernel with parts of the candidate path cut out (results are wrong then)
 __device__ int focr_v2s_variant;
 extern "C" int focr_debug_v2s_variant(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(focr_v2s_variant), &v, sizeof v) == hipSuccess ? 0 : 1; }
+// ... and how often the candidate path runs: [0] items, [1] visits (N-tiles with a candidate), [2] M-tiles looked into, [3] registers with a candidate
+__device__ unsigned long long focr_v2s_counts[4];
+extern "C" int focr_debug_v2s_counts(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(focr_v2s_counts), 32) != hipSuccess) return 1;
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    return reset && hipMemcpyToSymbol(HIP_SYMBOL(focr_v2s_counts), z, 32) != hipSuccess ? 1 : 0;
+}
+#define V2S_COUNT(i) v2s_cnt[i]++;
+#else
+#define V2S_COUNT(i)
 #endif
 #ifdef FOCR_V2S_PROF
 // experiment builds only (make hip EXTRA=-DFOCR_V2S_PROF; tools/prof2s.py): per-phase wave time (s_memtime ticks), summed over all waves
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         lane_off[j] = RPG == LAYOUT_W16 ? (uint32_t)r + (uint32_t)g * pitch
                       : RPG == LAYOUT_W8 ? (uint32_t)r + (uint32_t)(2 * g + (j & 1)) * pitch
                                          : (uint32_t)r + (uint32_t)(4 * g + j) * pitch;
+    const uint32_t r_key = (uint32_t)r << fmt.bt;  // the lane's window inside its M-tile, in key position
     uint32_t plane_off[NV];  // the lane's own window inside an M-tile's entries of plane v, in bytes (all planes of a pass span < 4 GiB: launch_scan_mfma)
 #pragma unroll
     for (int v = 0; v < NV; v++) plane_off[v] = (uint32_t)r * 2 + (uint32_t)v * (uint32_t)(P.stride * 2);
@@ -258,12 +269,14 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
     v4i afrag[MT][KSTEPS];
 #ifdef FOCR_V2S_VARIANTS
     const int variant = __builtin_amdgcn_readfirstlane(focr_v2s_variant);
+    uint32_t v2s_cnt[4] = {0, 0, 0, 0};
 #endif
 #ifdef FOCR_V2S_PROF
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
     for (uint32_t item; take.next(item);) {
         PROF2(5)  // waiting for the ticket
+        V2S_COUNT(0)
 #ifdef FOCR_V2S_PROF
         prof_acc[7]++;
 #endif
@@ -362,6 +375,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         for (uint32_t sgi = 0; sgi < segs.n; sgi++) {  // one segment = the N-tiles of one size class
             const uint32_t seg_end = segs.s[sgi].tile_end, sv = P.seg_value[sgi];
             const bool full = P.seg_full[sgi] != 0;  // false: the class's templates are all zero in the last K-step (12-byte rows, n_w <= 8)
+            const uint32_t dead_from = P.seg_dead_from[sgi];
             int ci[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -398,11 +412,19 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 #ifdef FOCR_V2S_VARIANTS
                     if (variant & 2) { asm volatile("s_nop 0"); continue; }
 #endif
-                    // The candidate path costs 0.33 of the kernel's 2.3 ms at C2 (3.8 M candidates; threshold sweep in
-                    // DESIGN.md), so it is kept short: ONE LDS read per visit for the lane's four template ids (lane (r, g),
-                    // register i: template 4g + i of the tile, window px + r; ~0 = dead / padding, never emits), one ballot per
-                    // register, and a key that is a scalar base per M-tile plus two lane terms.
-                    const v4i tg4 = reinterpret_cast<const v4i *>(tg_lds)[nt * 4 + g];
+                    // The candidate path is kept short (a sixth of the kernel at BASELINE configs[1], where six windows in ten that pass
+                    // are real matches): ONE LDS read per visit for the lane's four template ids (lane (r, g), register i: template
+                    // 4g + i of the tile, window px + r), one compare per register — its mask is the ballot — and a key whose high
+                    // word and low-word base are formed once per M-tile (x = px + r and the template id fill disjoint bit fields of
+                    // the low word: launch_v2s checks bt + bx <= 32), so a staged key costs one v_or3 and one LDS write.
+                    V2S_COUNT(1)
+                    v4i tg4 = reinterpret_cast<const v4i *>(tg_lds)[nt * 4 + g];
+                    if (nt >= dead_from) {  // the class's last tiles: dead / padding slots (id ~0) never emit.  Wave-uniform, rare
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc[mt][i] = tg4[i] == -1 ? -1 : acc[mt][i];
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         if (!pv[mt]) continue;  // past the end of the enumeration (a repeat of the last live M-tile): wave-uniform
@@ -411,14 +433,17 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 #ifdef FOCR_V2S_VARIANTS
                         if (variant & 4) { asm volatile("s_nop 0"); continue; }
 #endif
+                        V2S_COUNT(2)
                         uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
                         asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
-                        const uint64_t kbase = fmt.pack(page_base + pg, yy, xx, 0) + ((uint64_t)r << fmt.bt);  // x = px + r < 2^bx: no carry into y
+                        const uint64_t kb = fmt.pack(page_base + pg, yy, xx, 0);  // scalar
+                        const uint32_t k_hi = (uint32_t)(kb >> 32), k_lo = (uint32_t)kb | r_key;
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const bool ok = acc[mt][i] > 0 && tg4[i] != -1;
+                            const bool ok = acc[mt][i] > 0;
                             const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
                             if (!okmask) continue;  // wave-uniform
+                            V2S_COUNT(3)
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
                             if (wcount + cnt > WBUF) {
                                 PROF2(3)
@@ -430,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
 #endif
                             }
                             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
-                            if (ok) wbuf[wcount + pos] = kbase + (uint32_t)tg4[i];
+                            if (ok) reinterpret_cast<uint2 *>(wbuf)[wcount + pos] = uint2{k_lo | (uint32_t)tg4[i], k_hi};
                             wcount += cnt;
                         }
                     }
@@ -444,6 +469,10 @@ __global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
         PROF2(2)
     }
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
+#ifdef FOCR_V2S_VARIANTS
+    if (lane == 0)
+        for (int i = 0; i < 4; i++) atomicAdd(&focr_v2s_counts[i], (unsigned long long)v2s_cnt[i]);
+#endif
 #ifdef FOCR_V2S_PROF
     if (lane == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&focr_prof2[i], prof_acc[i]);
@@ -484,6 +513,8 @@ extern "C" int focr_debug_prof2(unsigned long long *out, int reset) {
 #endif
 
 int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, unsigned n_cus) {
+    // the kernel forms a key's low word from disjoint bit fields (x and template id); banks hold <= 65535 templates, pages <= 65535 px
+    if (c->fmt.bt + c->fmt.bx > 32) return fail(c, FOCR_ERR_INVALID, "scan_mfma2s: key format too wide");
     const uint32_t nvp = A3.nv <= 1 ? 1 : (A3.nv <= 2 ? 2 : 4);
 #define CASE2S(K, R)                                            \
     case (K) * 10 + (R):                                        \
