@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--scan-cus", type=int, default=-1,
                     help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
                          "of them (the rest is left to the other contexts' small kernels; flat optimum 192..224 of 256: DESIGN.md section 5)")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
                          "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
                          "overlap another's MFMA scan; 1 = strictly one batch at a time")

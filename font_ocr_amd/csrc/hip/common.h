@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,6 +90,19 @@ struct RowHist {
     uint32_t bt, bx;     // x = (key >> bt) & (2^bx - 1)
     uint32_t seg_shift, n_seg;
 };
+// Everything a scan needs zeroed, in ONE launch (clear_kernel, scan_mfma.hip).  A hipMemsetAsync costs the submitting thread several
+// times a kernel launch (six of them stood between a batch's hand-over and its first kernel: ~0.3 ms of a 1.9 ms step).
+struct ClearList {
+    void *p[8];       // 8-byte aligned
+    uint32_t n8[8];   // 8-byte words
+    uint32_t n;
+    void add(void *ptr, size_t bytes) {
+        p[n] = ptr;
+        n8[n] = (uint32_t)((bytes + 7) / 8);
+        n++;
+    }
+};
+
 __host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
     const uint32_t line = (uint32_t)(key >> h.shift), x = (uint32_t)(key >> h.bt) & ((1u << h.bx) - 1u);
     return (((line >> h.by) - h.page_base) * h.r_h + (line & ((1u << h.by) - 1u))) * h.n_seg + (x >> h.seg_shift);
@@ -100,8 +115,39 @@ __host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
 constexpr uint32_t COUNTER_WORDS = 64, QUEUE_XCDS = 8, QUEUE_STRIDE = 32, MAX_SCAN_QUEUES = 128;
 constexpr size_t COUNTER_BYTES = (COUNTER_WORDS + (size_t)MAX_SCAN_QUEUES * QUEUE_XCDS * QUEUE_STRIDE) * sizeof(uint32_t);
 
+namespace focr {
+// Scans of one executor (pipe.hip) are queued in TICKET order.  The contexts of a device take turns with the persistent scan
+// kernel (launch_scan_mfma); left to the order in which their host threads happen to get there, a batch submitted later can
+// scan — and so finish — before an earlier one, and a host that retires batches in submission order then holds the early
+// finisher's lane idle until the straggler is done: the lanes fall into step, all statistics kernels run at once and nothing
+// scans meanwhile (measured at BASELINE configs[1], three and four batches in flight: 0.34-0.43 ms without a scan per 1.9 ms
+// step).  A ticket passes the gate when every earlier ticket has queued its scan (or ended without one).
+struct TurnGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next = 1;  // the lowest ticket that has not passed yet
+    void enter(uint64_t t) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return next >= t; });
+    }
+    void leave(uint64_t t) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (next == t) next = t + 1;
+        }
+        cv.notify_all();
+    }
+    void skip(uint64_t t) {  // a batch that ends without a scan turn (error, direct mode) must not hold up the later ones
+        enter(t);
+        leave(t);
+    }
+};
+}  // namespace focr
+
 struct focr_ctx {
     int device = -1;
+    focr::TurnGate *turn_gate = nullptr;  // set by the executor that drives this context (pipe.hip), with the batch's ticket
+    uint64_t turn_ticket = 0;
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -156,6 +202,7 @@ struct focr_ctx {
     // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded
     size_t n_pages = 0, r_w = 0, r_h = 0, pitch = 0, rows_alloc = 0;
     size_t pages_capacity = 0;  // pages d_pages was allocated for (>= n_pages)
+    unsigned n_cus = 0;         // compute units of the device (read once, focr_ctx_create)
     unsigned scan_cus = 0;      // CUs the persistent scan kernel may occupy, 0 = all (focr_ctx_set_scan_cus)
     uint8_t *d_pages = nullptr;
     uint8_t *d_pages_i8 = nullptr;  // the same pages as int8 (ink - 128, i.e. byte ^ 0x80; padding = 0x80): the MFMA prefilter's window operand,
@@ -249,6 +296,7 @@ int fail(focr_ctx *ctx, int code, const std::string &msg);
 // launchers implemented in the .hip files
 int launch_scan_direct(focr_ctx *ctx, float threshold, int rust_formula);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
+int launch_clear(focr_ctx *c, const focr::ClearList &l);  // zero every region of the list in one launch (scan_mfma.hip)
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
 int finish_results(focr_ctx *c);  // wait for the stream once and read the result sizes of the last scan / process_hits

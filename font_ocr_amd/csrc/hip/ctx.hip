@@ -232,6 +232,9 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
     c->device = device;
     auto init = [&]() -> int {
         FOCR_HIP(c, hipSetDevice(device));
+        int cus = 0;
+        FOCR_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        c->n_cus = (unsigned)std::max(cus, 1);
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
         FOCR_HIP(c, hipMalloc(&c->d_counter, COUNTER_BYTES));

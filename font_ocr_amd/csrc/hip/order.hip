@@ -445,9 +445,7 @@ int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t
              *unit_end = unit_begin + max_units;
     c->d_hkeys = hkeys;
     c->d_hsims = hsims;
-    hipDeviceProp_t prop;
-    FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
-    const unsigned unit_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((max_units + 3) / 4, (size_t)prop.multiProcessorCount * 4));
+    const unsigned unit_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((max_units + 3) / 4, (size_t)c->n_cus * 4));
     const size_t lds = (size_t)4 * T * 4;
     hipLaunchKernelGGL(order_units_kernel, dim3(1), dim3(1024), 0, c->stream, hkeys, n_p, (uint64_t)ub, c->fmt, (uint32_t)c->sub_p0, n_pages, page_start, page_unit0,
                        unit_page, unit_begin, unit_end);

@@ -65,6 +65,7 @@ struct PipeLane {
 }  // namespace focr
 
 struct focr_pipe {
+    mutable focr::TurnGate gate;  // the lanes' scans are queued in ticket order (common.h)
     bool fetch = false;
     std::vector<focr::PipeLane *> lanes;
     std::mutex mu;  // guards next_ticket
@@ -84,6 +85,13 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
             job = L->job;
         }
         focr_ctx *c = L->ctx;
+        uint64_t ticket;
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            ticket = L->ticket;
+        }
+        c->turn_gate = &P->gate;
+        c->turn_ticket = ticket;
         int rc = FOCR_OK;
         if (job.pages) {
             rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
@@ -92,6 +100,7 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
                                    : focr_pages_upload(c, 0, job.n_pages, (const uint8_t *)job.pages, job.invert);
         }
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
+        P->gate.skip(ticket);  // no-op when the scan took its turn; a batch that ended before must not hold up the later tickets
         if (rc == FOCR_OK && job.post) rc = focr_process_hits(c, job.anchor_threshold, job.overlap);
         if (rc == FOCR_OK) rc = focr_sync(c);  // the batch's one host wait: scan and process_hits queue everything without waiting
         if (rc == FOCR_OK && job.post && job.chars_out) {  // copy-out on the context's own stream: ordered, no other queue involved

@@ -180,7 +180,7 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     // grow-only device scratch (no allocation in the steady state); outputs are sized by their bounds: characters <= hits,
     // lines <= page rows
     const size_t n_rows_total = n_pages * c->r_h;
-    uint8_t *keep_row = (uint8_t *)c->post_keep.ensure(c, n_rows_total);
+    uint8_t *keep_row = (uint8_t *)c->post_keep.ensure(c, n_rows_total + 8);
     uint32_t *choice = (uint32_t *)c->post_choice.ensure(c, (ub + 1) * 4);
     uint64_t *packed = (uint64_t *)c->post_packed.ensure(c, (n_rows_total + 1) * 8);    // per row: 1<<32 | groups
     uint64_t *scanned = (uint64_t *)c->post_scanned.ensure(c, (n_rows_total + 1) * 8);
@@ -191,8 +191,12 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     if (!line_b || !keep_row || !choice || !packed || !scanned || !d_page_off || !d_line_off || !d_chars)
         return fail(c, FOCR_ERR_NOMEM, "focr_process_hits: hipMalloc failed");
     const uint8_t *keep = (const uint8_t *)c->ord_keep.p;
-    FOCR_HIP(c, hipMemsetAsync(keep_row, 0, n_rows_total, c->stream));
-    FOCR_HIP(c, hipMemsetAsync(packed, 0, (n_rows_total + 1) * 8, c->stream));
+    {
+        ClearList clear{};  // one launch instead of two memsets (common.h)
+        clear.add(keep_row, n_rows_total);
+        clear.add(packed, (n_rows_total + 1) * 8);
+        if (int rc = launch_clear(c, clear)) return rc;
+    }
     const unsigned nb = (unsigned)((ub + 255) / 256);
     if (ub)
         hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, c->d_n_hits, (uint64_t)ub, c->fmt,

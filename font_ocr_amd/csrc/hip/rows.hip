@@ -363,15 +363,18 @@ bool rows_applicable(const focr_ctx *c) {
 }
 
 // before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
-int rows_begin(focr_ctx *c) {
+int rows_begin(focr_ctx *c, ClearList &clear) {
     const size_t n_rows = row_buckets(c);  // "rows" below: buckets = page rows x x-segments
     const size_t padded = (n_rows + 1 + 3) / 4 * 4 + 4;  // row_prefix_kernel moves 16 bytes at a time
     uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, padded * 4);
     if (!cnt || !c->rows_base.ensure(c, padded * 4) || !c->rows_fill.ensure(c, padded * 4) || !c->rows_hits.ensure(c, padded * 4) ||
         !c->rows_hbase.ensure(c, padded * 4))
         return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    FOCR_HIP(c, hipMemsetAsync(cnt, 0, padded * 4, c->stream));
-    FOCR_HIP(c, hipMemsetAsync(c->rows_hits.p, 0, padded * 4, c->stream));  // the padding behind the last row must read 0
+    uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4 + 8);  // [0]: length of the list of large buckets (rows_tail)
+    if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    clear.add(cnt, padded * 4);
+    clear.add(c->rows_hits.p, padded * 4);  // the padding behind the last row must read 0
+    clear.add(big, 8);
     uint32_t seg_shift, n_seg;
     row_segments(c, &seg_shift, &n_seg);
     c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0, c->fmt.bt, c->fmt.bx, seg_shift, n_seg};
@@ -405,9 +408,7 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
     }
     float *bsims = (float *)c->scan_pos.ensure(c, (ub_c + 1) * 4);
     if (!bsims) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    hipDeviceProp_t prop;
-    FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
-    const unsigned cus = (unsigned)prop.multiProcessorCount;
+    const unsigned cus = c->n_cus;
     const uint32_t *base = (const uint32_t *)c->rows_base.p;
     uint32_t *fill = (uint32_t *)c->rows_fill.p, *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
     if (ub_c) {
@@ -426,9 +427,7 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         uint32_t xs = 0;
         while ((seg_w >> xs) > XBINS) xs++;
         const uint32_t n_bins = seg_w >> xs;
-        uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4);
-        if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-        FOCR_HIP(c, hipMemsetAsync(big, 0, 4, c->stream));
+        uint32_t *big = (uint32_t *)c->rows_big.p;  // allocated and zeroed in rows_begin
         auto k1 = row_sort_kernel<1024, 4, false>;
         auto k2 = row_sort_kernel<4096, 1, true>;
         const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;

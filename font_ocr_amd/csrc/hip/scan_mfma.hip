@@ -48,7 +48,7 @@ int compact_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, con
 int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c);
 // rows.hip: the row path of the tail
 bool rows_applicable(const focr_ctx *c);
-int rows_begin(focr_ctx *c);
+int rows_begin(focr_ctx *c, ClearList &clear);
 int rows_prefix(focr_ctx *c);
 uint32_t rows_capacity_for(uint64_t row_max);
 int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class);
@@ -57,6 +57,23 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
 // ---------------------------------------------------------------------------------------------
 // 1. window statistics -> threshold planes (or the legacy int32 tables)
 //
+// Everything a scan needs zeroed, in one launch (ClearList, common.h)
+__global__ __launch_bounds__(256) void clear_kernel(const ClearList l) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    for (uint32_t r = 0; r < l.n; r++) {
+        uint64_t *p = reinterpret_cast<uint64_t *>(l.p[r]);
+        for (uint32_t i = tid; i < l.n8[r]; i += step) p[i] = 0;
+    }
+}
+int launch_clear(focr_ctx *c, const ClearList &l) {
+    size_t words = 0;
+    for (uint32_t r = 0; r < l.n; r++) words += l.n8[r];
+    if (!words) return FOCR_OK;
+    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)std::min<size_t>(1024, (words + 1023) / 1024)), dim3(256), 0, c->stream, l);
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
 // Separable sliding sums: a block stages a (64 + n_w) x (32 + n_h - 1) byte tile, computes the horizontal
 // n_w-sums H (and H2 of squares) of every tile row once (v_dot4 on masked dwords), then each thread slides a
 // vertical n_h-window down its column: S(y+1) = S(y) + H(y+n_h) - H(y).  ~40 instructions per window instead
@@ -604,8 +621,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
     if (rc) return rc;
     size_t want_cand = std::max<size_t>(c->cand_capacity, std::max<size_t>(1u << 21, c->sub_np * 131072));
     if (c->estimated) want_cand = std::max(want_cand, c->est_cand);
-    hipDeviceProp_t prop;
-    FOCR_HIP(c, hipGetDeviceProperties(&prop, c->device));
 
     for (int attempt = 0; attempt < 4; attempt++) {
         if (c->cand_capacity < want_cand) {
@@ -618,9 +633,10 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         }
         c->counters[3] = 0;
         c->launches_reset();
-        FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, COUNTER_BYTES, c->stream));  // counters + the scan kernels' item queues
+        ClearList clear{};  // everything the scan needs zeroed: one launch (launch_clear), in front of the first kernel
+        clear.add(c->d_counter, COUNTER_BYTES);  // counters + the scan kernels' item queues
         c->scan_queues_used = 0;
-        FOCR_HIP(c, hipMemsetAsync(c->d_res, 0, 7 * sizeof(uint64_t), c->stream));
+        clear.add(c->d_res, 7 * sizeof(uint64_t));
         // Sizes.  Exact mode: the host reads the candidate count after the scan kernels and the hit count after the
         // verify (two waits), so every later phase runs on exact sizes.  Estimated mode (ctx.hip: same setup as the
         // previous scan): the counts stay on the device, grids and buffers take the previous counts + a margin (4 .. 20 %, ctx.hip) as bounds,
@@ -635,14 +651,17 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             use_rows = c->est_row_max != 0 && row_cap != 0;
         }
         c->row_hist = RowHist{};
-        if (use_rows && (rc = rows_begin(c))) return rc;
+        if (use_rows && (rc = rows_begin(c, clear))) return rc;
         // legacy tail, estimated sizes: unused candidate slots hold the largest key so that the radix sort leaves them at the end
         if (c->estimated && !use_rows) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // `sim > +inf` is never true (NaN thresholds arrive here as +inf, focr_scan): no statistics, no scan, zero candidates
         // (kappa would be inf - inf = NaN and every window of every live tile a candidate for verify to reject)
         const bool nothing = !(thr_d < (double)INFINITY);
-        if (nothing) FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        if (nothing) {
+            if ((rc = launch_clear(c, clear))) return rc;
+            FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        }
         if (!nothing) {
         // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
         size_t tiles_total = 0;
@@ -663,10 +682,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (nt >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
             tiles_total += (size_t)nt;
         }
-        uint8_t *live = (uint8_t *)c->scan_live.ensure(c, tiles_total + 16);
+        uint8_t *live = (uint8_t *)c->scan_live.ensure(c, tiles_total + 24);
         uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
         if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
-        FOCR_HIP(c, hipMemsetAsync(live, 0, tiles_total + 16, c->stream));
+        clear.add(live, tiles_total + 16);
+        if ((rc = launch_clear(c, clear))) return rc;
         // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
         const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // f16 values per plane
         std::vector<int> two(c->supers.size(), 0);
@@ -738,6 +758,16 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         // contexts' small kernels use the CUs left free by focr_ctx_set_scan_cus.
         if (c->supers.size() > 40) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many super-classes");
         {
+        // an executor's batches scan in ticket order (TurnGate, common.h): wait for the earlier tickets' scans to be queued
+        struct GatePass {
+            focr_ctx *c;
+            explicit GatePass(focr_ctx *c_) : c(c_) {
+                if (c->turn_gate) c->turn_gate->enter(c->turn_ticket);
+            }
+            ~GatePass() {
+                if (c->turn_gate) c->turn_gate->leave(c->turn_ticket);
+            }
+        } gate_pass(c);
         ScanTurns &tn = scan_turns[(unsigned)c->device % 64];
         std::lock_guard<std::mutex> turn(tn.mu);  // held only while enqueueing
         if (!tn.init) {
@@ -799,7 +829,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 L.n_tiles16 = t1 - t0;
                 L.q_offset = su.q_offset + (size_t)t0 * su.ksteps * 1024;
                 L.tg_offset = su.tg_offset + (size_t)t0 * 16;
-                const unsigned cus = c->scan_cus ? std::min(c->scan_cus, (unsigned)prop.multiProcessorCount) : (unsigned)prop.multiProcessorCount;
+                const unsigned cus = c->scan_cus ? std::min(c->scan_cus, c->n_cus) : c->n_cus;
                 if (c->scan_queues_used >= MAX_SCAN_QUEUES) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many scan passes for one call (bank too large)");
                 L.queue = c->d_counter + COUNTER_WORDS + (size_t)(c->scan_queues_used++) * QUEUE_XCDS * QUEUE_STRIDE;
                 if (two[si]) {

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 #ifndef FOCR_V2S_NW
 #define FOCR_V2S_NW 16  // waves per workgroup (one workgroup per CU); experiment builds: make hip EXTRA=-DFOCR_V2S_NW=12
 #endif
+#ifndef FOCR_V2S_OCC
+#define FOCR_V2S_OCC 4  // waves per SIMD the register budget allows (128 VGPRs); experiment builds: 5 = 96 VGPRs, a fifth wave slot per SIMD left to other kernels
+#endif
 #ifdef FOCR_V2S_VARIANTS
 // experiment builds only: timing of the kernel with parts of the candidate path cut out (results are wrong then)
 __device__ int focr_v2s_variant;
@@ -223,7 +226,7 @@ __device__ unsigned long long focr_prof2[8];
 #define PROF2(i)
 #endif
 template <int KSTEPS, int RPG, int MT, int NW, int NV>
-__global__ __launch_bounds__(NW * 64, 4) void scan_mfma2s_kernel(
+__global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const PlaneArgs P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
