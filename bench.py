@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--scan-cus", type=int, default=-1,
                     help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
                          "of them (the rest is left to the other contexts' small kernels; flat optimum 192..224 of 256: DESIGN.md section 5)")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
                          "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
                          "overlap another's MFMA scan; 1 = strictly one batch at a time")
@@ -213,7 +213,7 @@ def main():
     from font_ocr_amd import Bank, synth_pages
     from font_ocr_amd.bank import HIT_DTYPE
     from font_ocr_amd.searcher import SCAN_DIRECT, SCAN_MFMA, Scanner
-    from font_ocr_amd.shard import gather_chars
+    from font_ocr_amd.shard import CharGather
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -221,7 +221,14 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL's kernels on a high-priority stream: the collective's few workgroups must not queue behind the thousands of short
+        # workgroups of the batches' small kernels for a CU (the scan leaves an eighth of the chip to all of them)
+        pg_opts = None
+        try:
+            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:  # noqa: BLE001 - an older torch: default priority
+            pg_opts = None
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts)
 
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
     global R_W, R_H
@@ -300,29 +307,36 @@ def main():
     # them in the same order; each gather is asynchronous on RCCL's stream and is waited for one step later.
     gather_q = queue.Queue()
     gathered = {"chars": 0, "err": None}
+    gather_dbg = [0.0, 0.0, 0]  # seconds issuing gathers, seconds finishing the previous ones, gathers
 
     def gather_worker():
         torch.cuda.set_device(local_rank)  # the current device is per thread
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # keep off the legacy null stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))  # off the legacy null stream; high priority, as RCCL's
+        gather = CharGather(rank, world, dev, capacity=slot_bytes)  # every buffer of the exchange allocated once
         pending = []
         while True:
             item = gather_q.get()
             try:
                 def finish_oldest():
                     fin, slot = pending.pop(0)
-                    allc = fin()
+                    got = fin()
                     torch.cuda.current_stream(dev).synchronize()  # the gather has read the slot
                     slot_free[slot].set()
-                    gathered["chars"] = allc.numel() // HIT_DTYPE.itemsize if rank == 0 else 0
+                    gathered["chars"] = sum(got[1]) // HIT_DTYPE.itemsize if rank == 0 else 0
 
                 if item is None:  # drain request
                     while pending:
                         finish_oldest()
                 else:
                     slot, nbytes = item
-                    pending.append((gather_chars(out_bufs[slot][:nbytes], rank, world, dev, async_op=True), slot))
+                    t_a = time.perf_counter()
+                    pending.append((gather.start(out_bufs[slot][:nbytes]), slot))
+                    t_b = time.perf_counter()
                     while len(pending) > 1:
                         finish_oldest()
+                    gather_dbg[0] += t_b - t_a
+                    gather_dbg[1] += time.perf_counter() - t_b
+                    gather_dbg[2] += 1
             except Exception as e:  # noqa: BLE001 - reported by fence()
                 gathered["err"] = e
                 for ev_ in slot_free:  # never leave the submitter waiting
@@ -515,6 +529,11 @@ def main():
                     k["n"] += 1
         sc.set_scan_cus(scan_cus)
 
+    if use_dist and gather_dbg[2] and rank == 0:
+        print(f"[bench] gather thread per gather: issue {gather_dbg[0] / gather_dbg[2] * 1e3:.3f} ms (sizes exchange incl. its host read, staging copies, "
+              f"the collective's launch), waiting for the previous one {gather_dbg[1] / gather_dbg[2] * 1e3:.3f} ms; {gather_dbg[2]} gathers; "
+              f"torch allocator: {torch.cuda.memory_stats(dev).get('num_device_alloc', -1)} device allocations, "
+              f"{torch.cuda.memory_stats(dev).get('num_device_free', -1)} frees", file=sys.stderr)
     out = {
         "metric": "Mpixels/s scanned (95-glyph x --x-bits=2 bank)",
         "value": round(value, 2),

@@ -31,6 +31,7 @@
 // block in LDS in exactly the per-lane order the MFMA wants; the K layouts (how image rows map to 16-byte k-groups) are
 // in mfma_common.h.  The scan kernels are in scan_mfma2.hip / scan_mfma3.hip.
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -93,8 +94,9 @@ struct StatsOut {  // what a statistics launch writes for one size class
     void *out;     // OUT = 1: f16 threshold plane, OUT = 0: int32 negL table; [page][Lrows][Lpitch]
 };
 
-template <int OUT>
-__device__ __forceinline__ void stats_store(const StatsOut &o, size_t idx, bool emit, float Lf) {
+// IDX: uint32_t on the plane path (a pass's planes span < 4 GiB: launch_scan_mfma), size_t for the int32 tables
+template <int OUT, typename IDX>
+__device__ __forceinline__ void stats_store(const StatsOut &o, IDX idx, bool emit, float Lf) {
     if (OUT) {
         reinterpret_cast<uint16_t *>(o.out)[idx] = emit ? plane_value(o.p, Lf) : PLANE_NEVER;
     } else {
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 const uint32_t y = y0 + (threadIdx.x >> 6) * (STY / 4) + k;
                 if (y >= Lrows) break;
                 const size_t idx = ((size_t)page * Lrows + y) * Lpitch + x;
-                stats_store<OUT>(A, idx, false, 0.f);
-                if (PAIR) stats_store<OUT>(B, idx, false, 0.f);
+                stats_store<OUT, size_t>(A, idx, false, 0.f);
+                if (PAIR) stats_store<OUT, size_t>(B, idx, false, 0.f);
             }
         return;
     }
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
         }
     }
     __syncthreads();
-    const uint32_t col = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    // the wave's strip of window rows as a scalar: row numbers, LDS row offsets and the "row exists" tests below stay out of the vector unit
+    const uint32_t col = threadIdx.x & 63, strip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t x = x0 + col;
     if (x >= Lpitch) return;
     constexpr uint32_t PER = STY / 4;  // window rows per thread
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     // M-tile marks: one store per 16-lane group and window row, decided by ballot (blank paper is never scanned;
     // the reference prunes it too, src/ncc.rs:280-301).  Row y of the image is tile row y - 1.
     const bool mark_lane = (col & 15) == 0 && (x >> 4) < mtx;
-    const size_t live_i = ((size_t)page * n_rows + ya) * mtx + (x >> 4);  // entry of image row ya + 1
-    size_t idx = ((size_t)page * Lrows + ya) * Lpitch + x;  // the window's entry in the planes; one row further per step
+    const uint32_t live_i = (page * n_rows + ya) * mtx + (x >> 4);  // entry of image row ya + 1 (a pass has < 2^31 M-tiles: launch_scan_mfma)
+    typedef typename std::conditional<OUT == 1, uint32_t, size_t>::type idx_t;
+    idx_t idx = ((idx_t)page * Lrows + ya) * Lpitch + x;  // the window's entry in the planes; one row further per step
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++, idx += Lpitch) {
         const uint32_t y = ya + k;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             const float Wf = DROP ? dropped_column_W_upper(n_k, n_h, s_k, q1, q2) : 0.f;
             const bool emit = x_ok && y_ok && nz;
             bool any = emit;
-            stats_store<OUT>(A, idx, emit, threshold_f32(A.p, Vf, Wf));
+            stats_store<OUT, idx_t>(A, idx, emit, threshold_f32(A.p, Vf, Wf));
             if (PAIR) {  // the kept box as a size class of its own: (n_w - 1) x n_h, nothing dropped
                 bool nzk;
                 float Vkf;
@@ -222,10 +226,10 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 }
                 const bool emit_k = xk_ok && y_ok && nzk;
                 any |= emit_k;
-                stats_store<OUT>(B, idx, emit_k, threshold_f32(B.p, Vkf, 0.f));
+                stats_store<OUT, idx_t>(B, idx, emit_k, threshold_f32(B.p, Vkf, 0.f));
             }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(any);
-            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + (size_t)k * mtx - mtx] = 1;
+            if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + k * mtx - mtx] = 1;
         }
         if (k + 1 < PER) {  // slide down one row
             s += H[r0 + k + n_h][col] - H[r0 + k][col];
