@@ -7,6 +7,8 @@ cp = {
     "bench_c2_noise_kernel_stats.csv": "r03_kernel_stats_bench_c2_noise.csv", "bench_c2_noise_run.json": "r03_bench_c2_noise_rocprof_run.json",
     "bench_c3_kernel_stats.csv": "r03_kernel_stats_bench_c3_64pages.csv", "bench_c3_run.json": "r03_bench_c3_64pages_rocprof_run.json",
     "bench_c4_2048pages_1gpu.json": "r03_bench_c4_2048pages_1gpu.json", "bench_c2_upload.json": "r03_bench_c2_upload.json",
+    "bench_c2_force_gather.json": "r03_bench_c2_force_gather.json", "bench_c2_inflight4.json": "r03_bench_c2_inflight4.json",
+    "timeline_bench_c2.log": "r03_timeline_bench_c2.log", "scan_variants.log": "r03_scan_variants.log", "mfma_shape.log": "r03_mfma_shape.log",
     "fetch_pmc.csv": "r03_pmc_FETCH_SIZE_kbench_c2.csv", "write_pmc.csv": "r03_pmc_WRITE_SIZE_kbench_c2.csv", "mfma_pmc.csv": "r03_pmc_mfma_busy_kbench_c2.csv",
     "insts_pmc.csv": "r03_pmc_insts_kbench_c2.csv", "c5_product_pmc.csv": "r03_pmc_c5_product.csv", "c5_forms_pmc.csv": "r03_pmc_c5_forms.csv",
 }

@@ -20,6 +20,11 @@ stats bench_c2_noise $B --noise
 stats bench_c3 $B --config c3 --pages-per-gpu 64 --steps 12 --warmup 2
 python3 bench.py --no-cpu-baseline --no-e2e --config c4 --c4-pages 2048 --steps 3 --warmup 1 > $out/bench_c4_2048pages_1gpu.json 2> $out/bench_c4.err; say "c4 done"
 python3 bench.py --no-cpu-baseline --with-upload --steps 60 > $out/bench_c2_upload.json 2> $out/bench_c2_upload.err; say "upload done"
+python3 bench.py --no-cpu-baseline --no-e2e --force-gather --steps 60 > $out/bench_c2_force_gather.json 2> $out/bench_c2_force_gather.err; say "force-gather done"
+python3 bench.py --no-cpu-baseline --no-e2e --in-flight 4 --steps 60 > $out/bench_c2_inflight4.json 2> /dev/null; say "in-flight 4 done"
+bash tools/timeline.sh > $out/timeline_bench_c2.log 2>&1; say "timeline done"
+FOCR_HIP_LIB=$repo/tools/bin/libfocr_hip_var.so python3 tools/variants.py > $out/scan_variants.log 2>&1; say "variants done"
+tools/bin/mfma_shape > $out/mfma_shape.log 2>&1; say "mfma_shape done"
 pmc fetch "FETCH_SIZE" python3 $repo/tools/kbench.py
 pmc write "WRITE_SIZE" python3 $repo/tools/kbench.py
 pmc mfma "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" python3 $repo/tools/kbench.py
