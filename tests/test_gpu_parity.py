@@ -918,6 +918,19 @@ def test_compat_symbols_in_the_reference_call_pattern(bank_x2):
     print(f"380 drop-in calls: {t_gpu * 1e3:.0f} ms on the device path, {t_ref * 1e3:.0f} ms with the reference kernel on one core")
 
 
+def test_pipeline_ticket_gate_never_blocks_on_failed_or_direct_batches():
+    """tools/gate_check.py: the lanes queue their scans in ticket order (TurnGate); a batch that fails before its scan and a
+    direct-mode batch (no scan turn) between MFMA batches must not hold the later tickets up.  Child process with a time limit:
+    a deadlock must fail, not hang."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gate_check.py")], capture_output=True, text=True, timeout=90)
+    assert r.returncode == 0 and "gate ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_pipeline_soak_mfma_equals_direct():
     """tools/stress_pipeline.py: 60 different batches (sizes, geometries, thresholds, blank pages) through the three-lane
     pipeline — MFMA prefilter with item queues, estimated result sizes, scans taking turns — each compared with the direct
