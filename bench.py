@@ -308,6 +308,7 @@ def main():
     gather_q = queue.Queue()
     gathered = {"chars": 0, "err": None}
     gather_dbg = [0.0, 0.0, 0]  # seconds issuing gathers, seconds finishing the previous ones, gathers
+    main_dbg = [0.0, 0.0, 0.0, 0]  # the submitting thread: seconds waiting for the oldest batch, for a free output slot, inside submit; submits
 
     def gather_worker():
         torch.cuda.set_device(local_rank)  # the current device is per thread
@@ -364,7 +365,9 @@ def main():
         """Consume the oldest step in flight: its results stay on the device; with several ranks they are gathered."""
         nonlocal n_chars
         t = jobs.popleft()
+        t_w = time.perf_counter()
         c_ = pipe.wait(t)
+        main_dbg[0] += time.perf_counter() - t_w
         if timed:
             for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
                 k = kern.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
@@ -394,10 +397,15 @@ def main():
         if use_dist:
             slot = next_slot[0] % len(out_bufs)
             next_slot[0] += 1
+            t_s = time.perf_counter()
             slot_free[slot].wait()  # its previous gather (2 * n_ctx steps ago) has read it
             slot_free[slot].clear()
+            t_u = time.perf_counter()
             t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, chars_out=(out_bufs[slot].data_ptr(), out_bufs[slot].numel()),
                             device_ptr=device_ptr, shape=shape)
+            main_dbg[1] += t_u - t_s
+            main_dbg[2] += time.perf_counter() - t_u
+            main_dbg[3] += 1
             slot_of[t] = slot
         else:
             t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, device_ptr=device_ptr, shape=shape)
@@ -533,7 +541,9 @@ def main():
         print(f"[bench] gather thread per gather: issue {gather_dbg[0] / gather_dbg[2] * 1e3:.3f} ms (sizes exchange incl. its host read, staging copies, "
               f"the collective's launch), waiting for the previous one {gather_dbg[1] / gather_dbg[2] * 1e3:.3f} ms; {gather_dbg[2]} gathers; "
               f"torch allocator: {torch.cuda.memory_stats(dev).get('num_device_alloc', -1)} device allocations, "
-              f"{torch.cuda.memory_stats(dev).get('num_device_free', -1)} frees", file=sys.stderr)
+              f"{torch.cuda.memory_stats(dev).get('num_device_free', -1)} frees; submitting thread per step: waiting for the oldest batch "
+              f"{main_dbg[0] / max(main_dbg[3], 1) * 1e3:.3f} ms, for a free output slot {main_dbg[1] / max(main_dbg[3], 1) * 1e3:.3f} ms, in submit "
+              f"{main_dbg[2] / max(main_dbg[3], 1) * 1e3:.3f} ms", file=sys.stderr)
     out = {
         "metric": "Mpixels/s scanned (95-glyph x --x-bits=2 bank)",
         "value": round(value, 2),
