@@ -111,7 +111,7 @@ __host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
 }  // namespace focr
 
 // Item queues of the persistent scan kernels (scan_mfma2.hip): one per launch, QUEUE_XCDS counters QUEUE_STRIDE dwords
-// apart, all zeroed by the one memset that clears the counters at the start of a scan.
+// apart, all zeroed with the counters by the clear launch at the start of a scan (ClearList).
 constexpr uint32_t COUNTER_WORDS = 64, QUEUE_XCDS = 8, QUEUE_STRIDE = 32, MAX_SCAN_QUEUES = 128;
 constexpr size_t COUNTER_BYTES = (COUNTER_WORDS + (size_t)MAX_SCAN_QUEUES * QUEUE_XCDS * QUEUE_STRIDE) * sizeof(uint32_t);
 

@@ -149,7 +149,7 @@ __host__ __device__ inline int prefilter_cin(float S, float v) {
 // with one item per ticket the queue itself set a floor of ~1 ms under the launch (round 2: 1.26 ms for a 6-N-tile bank whose
 // MFMAs take 0.3 ms).  A wave whose range is exhausted goes on with the next XCD's; it stops once it has seen every range
 // exhausted, which every wave reaches after at most n_xc extra requests.
-// The queue (QUEUE_XCDS counters, QUEUE_STRIDE dwords apart) is zeroed by the memset that opens every scan (launch_scan_mfma).
+// The queue (QUEUE_XCDS counters, QUEUE_STRIDE dwords apart) is zeroed by the clear launch that opens every scan (launch_scan_mfma, ClearList).
 #ifndef FOCR_ITEMS_PER_TICKET
 #define FOCR_ITEMS_PER_TICKET 4
 #endif

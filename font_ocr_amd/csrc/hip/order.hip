@@ -10,8 +10,9 @@
 //   rank inside the (page, t) segment < cap   <- d_keep[hit]: what the reference's early stop keeps
 //   CSR match lists in (page, t, y, x) order  <- exactly what N x T reference calls return
 //
-// The radix sorts and the prefix sums are rocPRIM device primitives (plain library ops on ~1e6 keys, not the hot
-// path); everything else is hand-written.
+// That is the SORTING form (order_hits: the direct scan's unordered hits; order_sorted_hits_sort: banks above 4 096 templates);
+// its radix sorts and prefix sums are rocPRIM device primitives.  The MFMA scan's default is the COUNTING form further down
+// (order_sorted_hits: the row tail already delivers the hits sorted, and a hit's place in its call is a count, not a sort).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>

@@ -3,8 +3,9 @@
 // The reference parallelises over pages with a rayon pool (src/ncc.rs:839-847).  On the GPU the unit is a batch of
 // pages, and what has to overlap is one batch's latency-bound small kernels (statistics, sorts, verify, ordering,
 // process_hits) with another batch's MFMA scan: that needs the batches on different streams, driven by different
-// host threads (focr_scan has host round trips for the candidate / hit counts).  This file is that executor, so a
-// host in any language gets the overlap from submit / wait / release without writing thread code.
+// host threads (a batch has one host wait in the steady state, three in a setup's first scan).  This file is that executor,
+// so a host in any language gets the overlap from submit / wait / release without writing thread code.  The lanes queue their
+// persistent scan kernels in TICKET order (TurnGate, common.h), so batches finish in the order they were submitted.
 // DESIGN.md section 5 ("Batches in flight") has the measurements.
 #include <condition_variable>
 #include <mutex>

@@ -4,32 +4,35 @@
 //     sim = num / (norm_n * norm_p),  num = sum_k a_k b_k - s_n s_p / n = sum_k a_k (b_k - mean_t)
 // and emits iff sim > thr.  Almost no (w, t) pair passes, so the device splits the work:
 //
-//  1. window statistics (stats_kernel): per size class and window, the exact integer sums s_p, s2_p and
-//     V = n*s2 - s^2; stored per window: the f16 norm sqrt(V / n) rounded towards zero, its sign = "the reference never
-//     emits here" (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN, src/ncc.rs:309-311).  (Legacy form, still
-//     used for size classes with more than 4 K-steps: negL(w) = -floor(kappa * norm_p(w)) as int32, or -REJECT.)
-//  2. MFMA prefilter (scan_mfma2.hip): every template is mean-centred, scaled by a bank-wide
-//     constant c/norm_n(t) and rounded to int8 with the rounding chosen so that sum_k bq_k = 0.
-//     G(w,t) = sum_k (a_k - 128) bq_k  (= sum_k a_k bq_k) is one v_mfma_i32_16x16x64_i8 chain over
-//     the window's bytes (16 templates x 16 windows, K = 64 bytes per instruction) with
-//     C-in = -(floor(kappa*norm_p(w)) - 2), so "D > 0" <=> G > kappa*norm_p.  Cauchy-Schwarz bounds the rounding error:
+//  1. window statistics (stats_kernel): per size class and window, the exact integer sums s_p, s2_p, V = n*s2 - s^2 (V > 0 <=> the
+//     reference's rnorm is finite, src/ncc.rs:309-311) and — for a class whose last column the MFMA does not multiply — that
+//     column's sums.  From them the window's prefilter THRESHOLD L(w) in f32 (mfma_common.h, "threshold planes"), stored as f16
+//     in units of a per-class power of two and rounded TOWARDS -INF ("threshold plane", 2 B per window and class); +inf where the
+//     reference never emits (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN).  A lower threshold only admits more
+//     candidates, so the directed rounding has no sign cases: the filter is conservative for negative --threshold too (round 2
+//     stored the window norm rounded towards zero and multiplied by kappa in the scan kernel, which RAISED the threshold for
+//     kappa < 0).  (Legacy form, still used for size classes with more than 4 K-steps: negL(w) = -(floor(L) - 2) as int32, or
+//     -REJECT.)  The kernel also marks every 16-window M-tile that has a live window; compact_live_tiles makes the work list.
+//  2. MFMA prefilter (scan_mfma2.hip): every template is mean-centred, scaled by a class-wide constant c/norm_n(t) and rounded
+//     to int8 with the rounding chosen so that sum_k bq_k = 0.  G(w,t) = sum_k (a_k - 128) bq_k  (= sum_k a_k bq_k) is one
+//     v_mfma_i32_16x16x64_i8 chain over the window's bytes (16 templates x 16 windows, K = 64 bytes per instruction) with
+//     C-in = -floor(S * plane value), so "D > 0" <=> G > L(w).  Cauchy-Schwarz bounds the rounding error:
 //         | c*num/norm_n - G | = | sum_k (a_k - mean_w) e_k | <= norm_p * ||e_t||_2
-//     hence sim > thr  ==>  G > (c*thr - max_t ||e_t||) * norm_p =: kappa * norm_p.  The filter
-//     has no false negatives; kappa carries an extra relative margin for the f64 roundings of
-//     the exact formula.  The stored f16 norm is a lower bound of norm_p: for kappa >= 0 that only lowers the threshold;
-//     for kappa < 0 (negative --threshold) kappa * norm_p falls as the norm grows, so the C-in is formed from the norm's
-//     upper bound instead (prefilter_cin, mfma_common.h; host model focr_debug_prefilter + tests/test_prefilter_host.py).
-//     Survivors (a few per 10^5 pairs) go to a candidate list.  (An experiment build puts a low-rank bound in front:
-//     scan_mfma3.hip.)
-//  3. exact verify (verify_kernel): the reference formula, operation for operation (common.h),
-//     on every candidate -> flags -> order.hip.
+//     hence sim > thr  ==>  G > (c*thr - max_t ||e_t||) * norm_p =: kappa * norm_p; kappa carries an extra relative margin for
+//     the f64 roundings of the exact formula.  Classes 9 or 13 px wide leave their last column to a second Cauchy-Schwarz term,
+//     L(w) = kappa * norm_p(w) - c * rho_max * dnorm(w), and take the next narrower K layout (column drop, mfma_common.h).  The
+//     filter has no false negatives (host model of the device arithmetic: prefilter_model.hip, tests/test_prefilter_host.py).
+//     Survivors go to a candidate list, counted per page-row bucket on the way.
+//  3. the row tail (rows.hip): candidates bucketed by page row, sorted per bucket, verified exactly — the reference formula,
+//     operation for operation (verify_candidate, mfma_common.h / common.h) — and compacted; order.hip derives the per-call
+//     ranks and the cap.  (verify_kernel below + the library radix sort = the legacy tail, kept as a fallback.)
 //
 // Sizes: every phase behind the scan kernel takes its element count from device memory; exact / estimated mode: see
 // launch_scan_mfma and ctx.hip (finish_results).
 //
-// Layout: one operand = windows (fragments straight from the page), the other = the quantised bank staged once per
+// Layout: one operand = windows (fragments straight from the page's int8 copy), the other = the quantised bank staged once per
 // block in LDS in exactly the per-lane order the MFMA wants; the K layouts (how image rows map to 16-byte k-groups) are
-// in mfma_common.h.  The scan kernels are in scan_mfma2.hip / scan_mfma3.hip.
+// in mfma_common.h.  The scan kernels are in scan_mfma2.hip.
 #include <algorithm>
 #include <type_traits>
 #include <cmath>

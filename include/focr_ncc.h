@@ -262,10 +262,11 @@ int focr_size_estimate_stats(focr_ctx_t *ctx, uint64_t *redone, double *margin, 
 /* ---- batches in flight ---------------------------------------------------
  * The executor form of the page parallelism of src/ncc.rs:839-847 (rayon
  * par_iter over pages): n contexts on one device, one worker thread each;
- * batches are handed out round-robin and complete in submission order.  One
- * batch's small kernels then overlap another's MFMA scan (DESIGN.md section 5:
- * 17.8 -> 22.6 Gpx/s at configs[1] with three contexts).  With more than one
- * context the scan kernel of each is capped to 3/4 of the CUs.
+ * batches are handed out round-robin and complete in submission order (the
+ * lanes queue their scan kernels in ticket order).  One batch's small kernels
+ * then overlap another's MFMA scan (24 -> 31 Gpx/s at
+ * configs[1] with three contexts).  With more than one context the scan kernel
+ * of each is capped to 7/8 of the CUs (focr_ctx_set_scan_cus).
  *
  *   focr_pipe_create(dev, 3, &p); focr_pipe_bank_upload(p, ...);
  *   for each batch b:   if (b >= 3) { wait(t[b-3], &ctx); read results from ctx; release(t[b-3]); }
