@@ -381,6 +381,49 @@ __device__ __forceinline__ bool verify_candidate_meta(uint64_t key, const Verify
     *sim_out = (float)sim;
     return ncc_emits(sim, va.thr_d);
 }
+// The same for banks whose templates are all at most 12 px wide: template rows of 12 bytes (three dwords) from LDS, page rows as
+// 12-byte loads, eight in flight — half the LDS and half the registers of the 16-byte form, so that TWO 1 024-thread workgroups
+// share a CU (verify_flat_kernel<2>, rows.hip).  Same arithmetic, same order of operations.
+typedef int v3i __attribute__((ext_vector_type(3)));
+typedef v3i v3i_b1 __attribute__((aligned(1)));
+__device__ __forceinline__ bool verify_candidate_narrow(uint64_t key, const VerifyArgs &va, const uint32_t *lds_rows, const VerifyMeta *meta, float *sim_out) {
+    const uint32_t page = va.fmt.page(key), t = va.fmt.t(key), x = va.fmt.x(key), y = va.fmt.y(key);
+    if (t >= va.n_templates || page >= va.n_pages || x >= va.r_w || y >= va.r_h) {  // cannot happen; would otherwise be a wild read
+        atomicOr(va.flags_word, 4ull);
+        *sim_out = 0.f;
+        return false;
+    }
+    const VerifyMeta c = meta[t];
+    const uint8_t *pg = va.pages + ((size_t)page * va.rows_alloc + y) * va.pitch + x;  // rows have >= 64 readable bytes past r_w
+    const uint32_t w = c.n_w;  // <= 12
+    uint32_t keep[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) keep[k] = w >= (uint32_t)(4 * k + 4) ? 0xffffffffu : (w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (w - 4 * k))) - 1u));
+    const uint32_t *nd = lds_rows + 3 * c.row0;
+    uint32_t acc = 0, s_p = 0, s2_p = 0;
+    for (uint32_t j0 = 0; j0 < c.n_h; j0 += 8) {  // rows past n_h are read (every page has 48 readable rows below it) but not accumulated
+        v3i a[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) a[jj] = *reinterpret_cast<const v3i_b1 *>(pg + (size_t)(j0 + jj) * va.pitch);
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const uint32_t j = j0 + jj;
+            if (j < c.n_h) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t aw = (uint32_t)a[jj][k] & keep[k], b = nd[3 * j + k];
+                    acc = __builtin_amdgcn_udot4(aw, b, acc, false);             // src/ncc.cpp:316-321
+                    s_p = __builtin_amdgcn_udot4(aw, 0x01010101u, s_p, false);   // patch_sum, src/ncc.rs:307
+                    s2_p = __builtin_amdgcn_udot4(aw, aw, s2_p, false);          // sum of squares, src/ncc.rs:308
+                }
+            }
+        }
+    }
+    const double rnorm_p = window_rnorm(s_p, (uint64_t)s2_p, (double)((uint32_t)c.n_w * c.n_h));
+    const double sim = ncc_similarity(acc, s_p, c.s_n, c.n_recip, c.rnorm_n, rnorm_p);
+    *sim_out = (float)sim;
+    return ncc_emits(sim, va.thr_d);
+}
 __device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs &va, float *sim_out) {
     return verify_candidate_t<false>(key, va, nullptr, sim_out);
 }

@@ -151,11 +151,9 @@ template <int CAP, int WAVES, bool LIST>
 #ifdef FOCR_TAIL_SMALL
 #define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64, LIST ? 1 : 8)
 #define VERIFY_THREADS 256
-#define VERIFY_BOUNDS __launch_bounds__(256, 8)
 #else
 #define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64)
 #define VERIFY_THREADS 1024
-#define VERIFY_BOUNDS __launch_bounds__(1024)
 #endif
 __global__ ROW_SORT_BOUNDS void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
                                                               uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t seg_mask, uint32_t xs, uint32_t n_bins,
@@ -261,17 +259,27 @@ __global__ ROW_SORT_BOUNDS void row_sort_kernel(uint32_t n_rows, const uint32_t 
 // addresser busy for most of the kernel's time (round 2: 0.22 ms for 3.8 M candidates).  LDS = true: the bank's verify
 // operand (16 bytes per template row) is staged in LDS once per workgroup — when all of it fits 144 KiB (BASELINE
 // configs[1]: 380 templates, 91 KB); larger banks keep the global loads (LDS = false).
-template <bool LDS>
-__global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap,
-                                                           const VerifyArgs va, uint32_t lds_rows, const RowHist rows, float *__restrict__ bsims,
-                                                           uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
-    // LDS: [template records: n_templates x 32 B][template rows, 16 B each, if LDS]
+// MODE 0: template rows from global memory · 1: from LDS, 16 bytes each · 2: from LDS, 12 bytes each (every template at most 12 px
+// wide and the whole operand within half a CU's LDS): 64 VGPRs, two workgroups per CU — the kernel waits on memory four fifths of
+// its time, and in flight it has only the CUs the scan leaves free, so waves per CU are what it runs on.
+template <int MODE>
+__global__ __launch_bounds__(VERIFY_THREADS, (MODE == 2 && VERIFY_THREADS == 1024) ? 8 : 1) void verify_flat_kernel(
+    const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
+    float *__restrict__ bsims, uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
+    // LDS: [template records: n_templates x 32 B][template rows, 16 B (MODE 1) or 12 B (MODE 2) each]
     extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    constexpr bool LDS = MODE == 1;
     VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
     v4i *needle_lds = verify_lds + 2 * va.n_templates;
+    uint32_t *needle12 = reinterpret_cast<uint32_t *>(needle_lds);
     for (uint32_t i = threadIdx.x; i < 2 * va.n_templates; i += blockDim.x) verify_lds[i] = reinterpret_cast<const v4i *>(va.vmeta)[i];
-    if (LDS)
+    if (MODE == 1)
         for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
+    if (MODE == 2)
+        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) {
+            const v4i r = va.needles16[i];
+            needle12[3 * i] = (uint32_t)r[0], needle12[3 * i + 1] = (uint32_t)r[1], needle12[3 * i + 2] = (uint32_t)r[2];
+        }
     __syncthreads();
     const unsigned long long n = min((unsigned long long)*total_p, cap);
     const int lane = threadIdx.x & 63;
@@ -284,7 +292,7 @@ __global__ VERIFY_BOUNDS void verify_flat_kernel(const uint64_t *__restrict__ bu
         const uint64_t key = key_next;
         if (i + stride < n) key_next = bucket[i + stride];
         float sim = 0.f;
-        const bool emit = valid && verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim);
+        const bool emit = valid && (MODE == 2 ? verify_candidate_narrow(key, va, needle12, meta, &sim) : verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim));
         if (valid) {
             bsims[i] = sim;
             bflags[i] = emit ? 1 : 0;
@@ -439,20 +447,30 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         FOCR_HIP(c, hipGetLastError());
     }
     if (ub_c) {
-        // the verify operand in LDS if all of it fits
+        // the verify operand in LDS if all of it fits: as 12-byte rows with two workgroups per CU when every template is at most
+        // 12 px wide and meta + rows take no more than half of the LDS, else as 16-byte rows, else from global memory
         size_t all_rows = 0;
-        for (const TemplateConst &tc : c->h_tconst) all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
+        uint32_t max_w = 0;
+        for (const TemplateConst &tc : c->h_tconst) {
+            all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
+            max_w = std::max<uint32_t>(max_w, tc.n_w);
+        }
         const size_t meta_bytes = c->n_templates * sizeof(VerifyMeta);  // <= 4096 templates here: 128 KiB at most
+        const bool narrow = VERIFY_THREADS == 1024 && max_w <= 12 && meta_bytes + all_rows * 12 <= ((size_t)80 << 10) - 256;
         const bool in_lds = meta_bytes + all_rows * 16 <= ((size_t)144 << 10);
-        const size_t lds = meta_bytes + (in_lds ? all_rows * 16 : 0);
+        const size_t lds = meta_bytes + (narrow ? all_rows * 12 : in_lds ? all_rows * 16 : 0);
         const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
-        if (in_lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<true>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
+        if (narrow) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(verify_flat_kernel<2>, dim3(std::max(1u, std::min<unsigned>((unsigned)((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS), 2 * cus))), dim3(VERIFY_THREADS), lds,
+                               c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va, (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
+        } else if (in_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(verify_flat_kernel<1>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
                                (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<false>, dim3(nb * (meta_bytes > ((size_t)64 << 10) ? 1 : 2)), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(verify_flat_kernel<0>, dim3(nb * (meta_bytes > ((size_t)64 << 10) ? 1 : 2)), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
                                va, 0u, c->row_hist, bsims, bflags, hits);
         }
         FOCR_HIP(c, hipGetLastError());
