@@ -56,15 +56,25 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
 // for the group's extent inside the chunk, a DPP max-reduction of the similarity order (f32::total_cmp), and a ballot
 // of the lanes that reach it — the highest such lane is the LAST maximum, which is what max_by keeps (:761-764).
 // Outputs: choice[b + k] = winning element of the row's k-th group, row_groups[row] = 1<<32 | number of groups.
+constexpr uint32_t WALK_ROWS = 16;  // (page, row) entries per wave
 __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ keys, const float *__restrict__ sims,
                                                   const uint8_t *__restrict__ keep, KeyFmt fmt, uint32_t n_rows_total,
                                                   int32_t overlap, const uint8_t *__restrict__ keep_row,
                                                   const uint32_t *__restrict__ line_b, const uint32_t *__restrict__ line_e,
                                                   uint32_t *__restrict__ choice, uint64_t *__restrict__ row_groups) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_rows_total) return;
-    if (!keep_row[wave]) return;  // keep_row / line_b / line_e / row_groups are [page][y] with pitch r_h == wave index
-    const uint64_t b = line_b[wave], e = line_e[wave];  // written by mark_anchor_rows for every row that has hits
+    // A wave looks at WALK_ROWS consecutive (page, row) entries at once and walks the anchored ones among them (one text line in
+    // fifteen rows at BASELINE configs[1]): one wave per ROW meant 92 160 waves per batch of which 6 000 had work — 77 us alone and
+    // 0.33 ms in flight for a few microseconds of arithmetic.
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t row_first = wave_id * WALK_ROWS;
+    if (row_first >= n_rows_total) return;
+    const uint32_t my_row = row_first + lane;
+    const bool mine = lane < WALK_ROWS && my_row < n_rows_total && keep_row[my_row] != 0;  // keep_row / line_b / line_e / row_groups are [page][y] with pitch r_h
+    const uint32_t my_b = mine ? line_b[my_row] : 0u, my_e = mine ? line_e[my_row] : 0u;  // written by mark_anchor_rows for every row that has hits
+    for (uint64_t todo = __builtin_amdgcn_ballot_w64(mine); todo; todo &= todo - 1) {
+    const int src = (int)__builtin_ctzll(todo);
+    const uint32_t wave = row_first + (uint32_t)src;  // the row this pass walks
+    const uint64_t b = (uint32_t)__builtin_amdgcn_readlane((int)my_b, src), e = (uint32_t)__builtin_amdgcn_readlane((int)my_e, src);
 
     uint32_t groups = 0;
     bool open = false;            // a group is open (carried across chunks)
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(256) void walk_lines(const uint64_t *__restrict__ k
         groups++;
     }
     if (lane == 0) row_groups[wave] = ((uint64_t)1 << 32) | groups;
+    }  // anchored rows of this wave
 }
 
 // one thread per hit slot: slot i of a row is the row's (i - line_b)-th output character if the row has that many groups
@@ -201,7 +212,7 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
     if (ub)
         hipLaunchKernelGGL(mark_anchor_rows, dim3(nb), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims, keep, c->d_n_hits, (uint64_t)ub, c->fmt,
                            anchor_threshold, (uint32_t)c->r_h, keep_row, line_b, line_e);
-    hipLaunchKernelGGL(walk_lines, dim3((unsigned)((n_rows_total * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
+    hipLaunchKernelGGL(walk_lines, dim3((unsigned)(((n_rows_total + WALK_ROWS - 1) / WALK_ROWS * 64 + 255) / 256)), dim3(256), 0, c->stream, c->d_hkeys, c->d_hsims,
                        keep, c->fmt, (uint32_t)n_rows_total, overlap, keep_row, line_b, line_e, choice, packed);
     int rc;
     if ((rc = exclusive_scan_u64(c, packed, scanned, n_rows_total + 1))) return rc;
