@@ -89,7 +89,10 @@ int launch_clear(focr_ctx *c, const ClearList &l) {
 //         the tile) down, which gives the kept box's sums and W.
 //   PAIR: the kept box is itself a size class of the pass (BASELINE configs[1]: 8x15 beside 9x15): its plane comes out of
 //         the same launch (its statistics are the kept box's), one launch instead of two.
-constexpr int STX = 64, STY = 32, SLDW = 21;
+#ifndef FOCR_STATS_STY
+#define FOCR_STATS_STY 32  // window rows per block (experiment builds: 64 = less halo, fewer blocks per CU)
+#endif
+constexpr int STX = 64, STY = FOCR_STATS_STY, SLDW = 21;
 static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h - 1) * (SLDW * 4 + STX * 4 + STX * 2); }
 
 struct StatsOut {  // what a statistics launch writes for one size class
