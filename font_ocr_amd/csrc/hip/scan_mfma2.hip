@@ -489,7 +489,7 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, un
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
     const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;
     const uint64_t n_items = (total_mt + MT - 1) / MT;
-    unsigned grid = (unsigned)std::min<uint64_t>(n_cus, (n_items + NW - 1) / NW);
+    unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)n_cus * (16 / NW), (n_items + NW - 1) / NW);  // 16 waves per CU: one workgroup, or two of 8 waves (experiment builds)
     auto kern = scan_mfma2s_kernel<KSTEPS, RPG, MT, NW, NV>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     uint64_t ksteps_issued = 0;  // K-steps per live M-tile: the last one is skipped for classes that are all zero there
