@@ -120,8 +120,8 @@ namespace focr {
 // kernel (launch_scan_mfma); left to the order in which their host threads happen to get there, a batch submitted later can
 // scan — and so finish — before an earlier one, and a host that retires batches in submission order then holds the early
 // finisher's lane idle until the straggler is done: the lanes fall into step, all statistics kernels run at once and nothing
-// scans meanwhile (measured at BASELINE configs[1], three and four batches in flight: 0.34-0.43 ms without a scan per 1.9 ms
-// step).  A ticket passes the gate when every earlier ticket has queued its scan (or ended without one).
+// scans meanwhile (seen in kernel timelines of BASELINE configs[1] after every drain of the pipeline).  A ticket passes the gate
+// when every earlier ticket has queued its scan (or ended without one).
 struct TurnGate {
     std::mutex mu;
     std::condition_variable cv;

@@ -7,6 +7,8 @@
 // so a host in any language gets the overlap from submit / wait / release without writing thread code.  The lanes queue their
 // persistent scan kernels in TICKET order (TurnGate, common.h), so batches finish in the order they were submitted.
 // DESIGN.md section 5 ("Batches in flight") has the measurements.
+#include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -65,8 +67,19 @@ struct PipeLane {
 
 }  // namespace focr
 
+struct PipeTrace {  // FOCR_PIPE_TRACE=1: host-side time stamps of every job, printed when the pipe is destroyed (us since creation)
+    uint64_t ticket;
+    unsigned lane;
+    double t_start, t_scan_queued, t_post_queued, t_synced, t_done;
+};
+
 struct focr_pipe {
     mutable focr::TurnGate gate;  // the lanes' scans are queued in ticket order (common.h)
+    bool trace = false;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    mutable std::mutex trace_mu;
+    mutable std::vector<PipeTrace> traces;
+    double now_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
     bool fetch = false;
     std::vector<focr::PipeLane *> lanes;
     std::mutex mu;  // guards next_ticket
@@ -93,6 +106,7 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
         }
         c->turn_gate = &P->gate;
         c->turn_ticket = ticket;
+        PipeTrace tr{ticket, 0, P->now_us(), 0, 0, 0, 0};
         int rc = FOCR_OK;
         if (job.pages) {
             rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
@@ -102,8 +116,11 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
         }
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
         P->gate.skip(ticket);  // no-op when the scan took its turn; a batch that ended before must not hold up the later tickets
+        tr.t_scan_queued = P->now_us();
         if (rc == FOCR_OK && job.post) rc = focr_process_hits(c, job.anchor_threshold, job.overlap);
+        tr.t_post_queued = P->now_us();
         if (rc == FOCR_OK) rc = focr_sync(c);  // the batch's one host wait: scan and process_hits queue everything without waiting
+        tr.t_synced = P->now_us();
         if (rc == FOCR_OK && job.post && job.chars_out) {  // copy-out on the context's own stream: ordered, no other queue involved
             const size_t bytes = focr_total_chars(c) * sizeof(focr_hit_t);
             if (bytes > job.chars_cap) {
@@ -137,6 +154,13 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
             R.line_char_off = job.post ? hl : nullptr;
             R.chars = job.post ? hh : nullptr;
         }
+        if (P->trace) {
+            tr.t_done = P->now_us();
+            for (size_t i = 0; i < P->lanes.size(); i++)
+                if (P->lanes[i] == L) tr.lane = (unsigned)i;
+            std::lock_guard<std::mutex> lk(P->trace_mu);
+            P->traces.push_back(tr);
+        }
         {
             std::lock_guard<std::mutex> lk(L->mu);
             L->rc = rc;
@@ -156,6 +180,7 @@ int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
     if (!out || n_contexts < 1 || n_contexts > 8) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_create: 1..8 contexts");
     *out = nullptr;
     focr_pipe *p = new focr_pipe();
+    p->trace = getenv("FOCR_PIPE_TRACE") != nullptr;
     hipDeviceProp_t prop;
     for (unsigned i = 0; i < n_contexts; i++) {
         PipeLane *L = new PipeLane();
@@ -181,6 +206,12 @@ int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out) {
 
 void focr_pipe_destroy(focr_pipe_t *p) {
     if (!p) return;
+    if (p->trace) {
+        std::sort(p->traces.begin(), p->traces.end(), [](const PipeTrace &a, const PipeTrace &b) { return a.ticket < b.ticket; });
+        for (const PipeTrace &t : p->traces)
+            fprintf(stderr, "[pipe] ticket %llu lane %u start %.0f scan queued +%.0f post queued +%.0f synced +%.0f done +%.0f\n", (unsigned long long)t.ticket, t.lane, t.t_start,
+                    t.t_scan_queued - t.t_start, t.t_post_queued - t.t_start, t.t_synced - t.t_start, t.t_done - t.t_start);
+    }
     for (PipeLane *L : p->lanes) {
         {
             std::unique_lock<std::mutex> lk(L->mu);
