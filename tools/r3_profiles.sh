@@ -13,7 +13,7 @@ pmc() {  # pmc <tag> "<counters>" <program args...> -> $out/<tag>_pmc.csv
   f=$(find $out/tmp_$tag -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/${tag}_pmc.csv; rm -rf $out/tmp_$tag
   say "$tag pmc done"
 }
-B="python3 $repo/bench.py --no-cpu-baseline --no-e2e"
+B="python3 $repo/bench.py --no-cpu-baseline --no-e2e --steps 100"  # the committed set was taken at 100 timed steps (the default is 300 now)
 stats bench_c2 $B
 stats bench_c2_serial $B --in-flight 1 --steps 40
 stats bench_c2_noise $B --noise
