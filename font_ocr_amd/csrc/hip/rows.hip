@@ -147,15 +147,9 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 //   LIST = true : the rows on `big`, with a larger CAP and one wave per workgroup; a row above that CAP sets the overflow bit
 //                 (batch redone through the legacy tail).
 constexpr uint32_t XBINS = 1024;
+constexpr unsigned VERIFY_THREADS = 1024;
 template <int CAP, int WAVES, bool LIST>
-#ifdef FOCR_TAIL_SMALL
-#define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64, LIST ? 1 : 8)
-#define VERIFY_THREADS 256
-#else
-#define ROW_SORT_BOUNDS __launch_bounds__(WAVES * 64)
-#define VERIFY_THREADS 1024
-#endif
-__global__ ROW_SORT_BOUNDS void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
+__global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
                                                               uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t seg_mask, uint32_t xs, uint32_t n_bins,
                                                               uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 bin starts, CAP placed sub-keys
@@ -263,7 +257,7 @@ __global__ ROW_SORT_BOUNDS void row_sort_kernel(uint32_t n_rows, const uint32_t 
 // wide and the whole operand within half a CU's LDS): 64 VGPRs, two workgroups per CU — the kernel waits on memory four fifths of
 // its time, and in flight it has only the CUs the scan leaves free, so waves per CU are what it runs on.
 template <int MODE>
-__global__ __launch_bounds__(VERIFY_THREADS, (MODE == 2 && VERIFY_THREADS == 1024) ? 8 : 1) void verify_flat_kernel(
+__global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_flat_kernel(
     const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
     float *__restrict__ bsims, uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
     // LDS: [template records: n_templates x 32 B][template rows, 16 B (MODE 1) or 12 B (MODE 2) each]
@@ -402,7 +396,7 @@ uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 4096 ? 4096u : 
 
 // scatter, per-row sort + verify, compaction: leaves the dense sorted hits in d_hit_keys / d_hit_sims_alt and their number in
 // d_res[6]; records ev[3] behind the verify
-int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class) {
+int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class, bool big_expected) {
     const uint32_t n_rows = (uint32_t)row_buckets(c);
     int rc;
     if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
@@ -442,7 +436,10 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
                            seg_w - 1, xs, n_bins, big, flags_word);
         FOCR_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k2, dim3(cus), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
+        // the buckets above 1 024 keys (the list `big`): one wave each over the whole chip where the last scan of this setup had any
+        // (or the exact count says so), else ONE wave — it still sorts whatever turns up, but a launch of `cus` single-wave
+        // workgroups that find an empty list cost 60 us of a lane's time in flight
+        hipLaunchKernelGGL(k2, dim3(big_expected ? cus : 1u), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
                            big, flags_word);
         FOCR_HIP(c, hipGetLastError());
     }
@@ -456,7 +453,7 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
             max_w = std::max<uint32_t>(max_w, tc.n_w);
         }
         const size_t meta_bytes = c->n_templates * sizeof(VerifyMeta);  // <= 4096 templates here: 128 KiB at most
-        const bool narrow = VERIFY_THREADS == 1024 && max_w <= 12 && meta_bytes + all_rows * 12 <= ((size_t)80 << 10) - 256;
+        const bool narrow = max_w <= 12 && meta_bytes + all_rows * 12 <= ((size_t)80 << 10) - 256;
         const bool in_lds = meta_bytes + all_rows * 16 <= ((size_t)144 << 10);
         const size_t lds = meta_bytes + (narrow ? all_rows * 12 : in_lds ? all_rows * 16 : 0);
         const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));

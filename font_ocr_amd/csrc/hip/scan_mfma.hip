@@ -55,7 +55,7 @@ bool rows_applicable(const focr_ctx *c);
 int rows_begin(focr_ctx *c, ClearList &clear);
 int rows_prefix(focr_ctx *c);
 uint32_t rows_capacity_for(uint64_t row_max);
-int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class);
+int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class, bool big_expected);
 
 
 // ---------------------------------------------------------------------------------------------
@@ -871,6 +871,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         size_t ub_c = c->ub_cand;
         if (use_rows && !nothing && (rc = rows_prefix(c))) return rc;
         if (nothing) use_rows = false;
+        bool big_expected = c->est_row_max > 1024;  // buckets above the row sort's first capacity class (rows_tail)
         if (!c->estimated) {
             unsigned long long n_cand = 0, row_max = 0;
             FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -879,6 +880,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (use_rows) {
                 row_cap = rows_capacity_for(row_max);
                 use_rows = row_cap != 0;  // a row beyond the largest capacity: legacy tail for this scan
+                big_expected = row_max > 1024;
             }
             if (n_cand > c->cand_capacity) {
                 if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
@@ -890,7 +892,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         c->row_cap = use_rows ? row_cap : 0;
         if (use_rows) {
             // 3a. row path: bucket by page row, sort + verify per row, compact (rows.hip), then the ordering pass
-            if ((rc = rows_tail(c, thr_d, n_cand_p, ub_c, row_cap))) return rc;
+            if ((rc = rows_tail(c, thr_d, n_cand_p, ub_c, row_cap, big_expected))) return rc;
             size_t ub_h = std::min(ub_c, c->est_hits);
             if (!c->estimated) {  // exact number of hits for the ordering pass
                 uint64_t hits = 0;

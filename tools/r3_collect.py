@@ -12,7 +12,11 @@ cp = {
     "fetch_pmc.csv": "r03_pmc_FETCH_SIZE_kbench_c2.csv", "write_pmc.csv": "r03_pmc_WRITE_SIZE_kbench_c2.csv", "mfma_pmc.csv": "r03_pmc_mfma_busy_kbench_c2.csv",
     "insts_pmc.csv": "r03_pmc_insts_kbench_c2.csv", "c5_product_pmc.csv": "r03_pmc_c5_product.csv", "c5_forms_pmc.csv": "r03_pmc_c5_forms.csv",
 }
+import sys
+TRAFFIC_ONLY = "--traffic-only" in sys.argv  # after tools/r3_traffic.sh: only the two PMC passes and profiles/r03_traffic.json
 for a, b in cp.items():
+    if TRAFFIC_ONLY and a not in ("fetch_pmc.csv", "write_pmc.csv"):
+        continue
     shutil.copy(os.path.join(R, a), os.path.join("profiles", b))
 
 def avg(f, kern, ctr):
@@ -44,6 +48,9 @@ t = {"kernel": "scan_mfma2s_kernel<2,2,4,16>", "workload_key": {"pages": 128, "r
      "note": "separate rocprofv3 --pmc passes over tools/kbench.py (tools/r3_profiles.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); unit KB",
      "sources": ["profiles/r03_pmc_FETCH_SIZE_kbench_c2.csv", "profiles/r03_pmc_WRITE_SIZE_kbench_c2.csv"]}
 json.dump(t, open("profiles/r03_traffic.json", "w"), indent=1)
+print("traffic", t["traffic_bytes"], t["FETCH_SIZE_KB_per_launch"], t["WRITE_SIZE_KB_per_launch"])
+if TRAFFIC_ONLY:
+    sys.exit(0)
 prod = json.load(open(R + "/c5_product.json"))
 forms = json.load(open(R + "/c5_forms.json"))
 json.dump({"what": "BASELINE configs[4], product kernel: int8 MFMA prefilter (scan_mfma2s_kernel) on the 256-template bank, 64 synthetic pages 608x720",
@@ -56,7 +63,6 @@ json.dump({"what": "BASELINE configs[4]: the scan's item loop instantiated with 
                    "256 zero-sum templates (tools/c5_forms.hip); equal candidate counts",
            "run": forms, "pmc_i8": pm(R + "/c5_forms_pmc.csv", "scan_form<false>"), "pmc_bf16": pm(R + "/c5_forms_pmc.csv", "scan_form<true>"),
            "source": "tools/c5_forms.hip, tools/r3_profiles.sh"}, open("profiles/r03_c5_bf16.json", "w"), indent=1)
-print("traffic", t["traffic_bytes"], t["FETCH_SIZE_KB_per_launch"], t["WRITE_SIZE_KB_per_launch"])
 print("kbench scan pmc", pm(R + "/mfma_pmc.csv", "scan_mfma2s"))
 ins = {c: avg(R + "/insts_pmc.csv", "scan_mfma2s", c)[0] for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")}
 print("insts", {k: round(v) for k, v in ins.items()}, "non-MFMA VALU per item", round((ins["SQ_INSTS_VALU"] - ins["SQ_INSTS_MFMA"]) / (ins["SQ_INSTS_MFMA"] / 192), 1),

@@ -1,5 +1,5 @@
 # only the two PMC passes behind profiles/r03_traffic.json (after an edit to the scan kernel's sources: the profile carries their
-# hash); then python tools/r3_collect.py
+# hash); then python tools/r3_collect.py --traffic-only
 repo=$PWD; out=$PWD/gpurun_out/r03; mkdir -p $out
 for pair in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   set -- $pair
