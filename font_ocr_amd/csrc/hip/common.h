@@ -96,10 +96,12 @@ struct ClearList {
     void *p[8];       // 8-byte aligned
     uint32_t n8[8];   // 8-byte words
     uint32_t n;
-    void add(void *ptr, size_t bytes) {
+    bool add(void *ptr, size_t bytes) {  // the region is zeroed in whole 8-byte words: its owner allocates up to 7 bytes of slack
+        if (n >= 8 || bytes / 8 >= 0xffffffffull) return false;
         p[n] = ptr;
         n8[n] = (uint32_t)((bytes + 7) / 8);
         n++;
+        return true;
     }
 };
 

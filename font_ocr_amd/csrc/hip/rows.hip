@@ -374,9 +374,9 @@ int rows_begin(focr_ctx *c, ClearList &clear) {
         return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
     uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4 + 8);  // [0]: length of the list of large buckets (rows_tail)
     if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    clear.add(cnt, padded * 4);
-    clear.add(c->rows_hits.p, padded * 4);  // the padding behind the last row must read 0
-    clear.add(big, 8);
+    if (!clear.add(cnt, padded * 4)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
+    if (!clear.add(c->rows_hits.p, padded * 4)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");  // the padding behind the last row must read 0
+    if (!clear.add(big, 8)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
     uint32_t seg_shift, n_seg;
     row_segments(c, &seg_shift, &n_seg);
     c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0, c->fmt.bt, c->fmt.bx, seg_shift, n_seg};

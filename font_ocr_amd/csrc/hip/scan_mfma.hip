@@ -644,9 +644,9 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         c->counters[3] = 0;
         c->launches_reset();
         ClearList clear{};  // everything the scan needs zeroed: one launch (launch_clear), in front of the first kernel
-        clear.add(c->d_counter, COUNTER_BYTES);  // counters + the scan kernels' item queues
+        if (!clear.add(c->d_counter, COUNTER_BYTES)) return fail(c, FOCR_ERR_INVALID, "scan_mfma: clear list full or region too large");  // counters + the scan kernels' item queues
         c->scan_queues_used = 0;
-        clear.add(c->d_res, 7 * sizeof(uint64_t));
+        if (!clear.add(c->d_res, 7 * sizeof(uint64_t))) return fail(c, FOCR_ERR_INVALID, "scan_mfma: clear list full or region too large");
         // Sizes.  Exact mode: the host reads the candidate count after the scan kernels and the hit count after the
         // verify (two waits), so every later phase runs on exact sizes.  Estimated mode (ctx.hip: same setup as the
         // previous scan): the counts stay on the device, grids and buffers take the previous counts + a margin (4 .. 20 %, ctx.hip) as bounds,
@@ -695,7 +695,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         uint8_t *live = (uint8_t *)c->scan_live.ensure(c, tiles_total + 24);
         uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
         if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
-        clear.add(live, tiles_total + 16);
+        if (!clear.add(live, tiles_total + 16)) return fail(c, FOCR_ERR_INVALID, "scan_mfma: clear list full or region too large");
         if ((rc = launch_clear(c, clear))) return rc;
         // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
         const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // f16 values per plane
