@@ -530,9 +530,9 @@ def main():
     iso = {}
     if rank == 0 and n_ctx > 1:
         sc.set_scan_cus(0)
-        for i in range(5):
+        for i in range(14):  # 4 to settle (the leg starts from an idle GPU), 10 measured
             run_step(sc)
-            if i >= 2:
+            if i >= 4:
                 for li in sc.launches():
                     k = iso.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0))
                     k["ms"] += li["ms"]
