@@ -78,9 +78,16 @@ def effective_cpus():
 def self_launch(args):
     """`--gpus N` (N > 1) without a launcher's RANK / WORLD_SIZE: start the N ranks here, one child process per GPU, before
     anything in this process has touched the GPU (a process that has initialised HIP must not exec or fork GPU users).
-    Rank 0's JSON line is this process's stdout; any rank failing fails the run."""
-    import socket
+    Rank 0's JSON line is this process's stdout.  The run FAILS FAST: all children are polled, the first one to exit non-zero
+    ends the run within seconds — the others are terminated (a rank waiting in a rendezvous or a collective for a dead peer
+    would otherwise sit there until the backend's own timeout), its exit code is returned and its last lines are repeated on
+    stderr.  Every line a rank writes to stderr (or, for ranks > 0, stdout) reaches this process's stderr as `[rank k] ...`.
+    The rendezvous is a file store in a private temporary directory (FOCR_BENCH_INIT): no port to reserve and lose."""
+    import shutil
+    import signal
     import subprocess
+    import tempfile
+    import threading
 
     if not args.dry_launch:
         import torch  # counting devices does not initialise the GPU
@@ -89,23 +96,115 @@ def self_launch(args):
         if have < args.gpus:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine shows {have} GPU(s); refusing to measure fewer GPUs than asked for\n")
             return 2
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(rcs):
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
-        return 1
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    return 0
+    store_dir = tempfile.mkdtemp(prefix="focr_bench_")
+    procs, tails, pumps, out0 = [], [], [], []
+
+    def pump(stream, rank, keep, sink):
+        for raw in iter(stream.readline, b""):
+            line = raw.decode(errors="replace").rstrip("\n")
+            keep.append(line)
+            del keep[:-40]
+            if sink is not None:
+                sink.append(line)
+            else:
+                sys.stderr.write(f"[rank {rank}] {line}\n")
+                sys.stderr.flush()
+        stream.close()
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):  # the driver's own time limit: never leave ranks behind
+        stop_all(signal.SIGTERM)
+        time.sleep(0.5)
+        stop_all(signal.SIGKILL)
+        shutil.rmtree(store_dir, ignore_errors=True)
+        os._exit(128 + signum)
+
+    old_handlers = {s_: signal.signal(s_, on_signal) for s_ in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), FOCR_BENCH_INIT="file://" + os.path.join(store_dir, "store"),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PYTHONUNBUFFERED="1")
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE if r == 0 else subprocess.STDOUT)
+            procs.append(p)
+            tails.append([])
+            if r == 0:  # rank 0: stdout is the JSON line (kept), stderr is forwarded
+                pumps.append(threading.Thread(target=pump, args=(p.stdout, r, [], out0), daemon=True))
+                pumps.append(threading.Thread(target=pump, args=(p.stderr, r, tails[r], None), daemon=True))
+            else:
+                pumps.append(threading.Thread(target=pump, args=(p.stdout, r, tails[r], None), daemon=True))
+        for t_ in pumps:
+            t_.start()
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = r
+                    break
+            else:
+                time.sleep(0.05)
+        if failed is None:
+            failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            rc = procs[failed].returncode
+            stop_all(signal.SIGTERM)
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            stop_all(signal.SIGKILL)
+            for p in procs:
+                p.wait()
+            for t_ in pumps:
+                t_.join(timeout=2.0)
+            sys.stderr.write(f"bench.py: rank {failed} exited with code {rc}; the other ranks were terminated. Its last lines:\n")
+            for line in tails[failed][-15:]:
+                sys.stderr.write(f"    [rank {failed}] {line}\n")
+            sys.stderr.flush()
+            return rc if 0 < rc < 256 else 1
+        for t_ in pumps:
+            t_.join(timeout=5.0)
+        sys.stdout.write("".join(line + "\n" for line in out0))
+        sys.stdout.flush()
+        return 0
+    finally:
+        for s_, h in old_handlers.items():
+            signal.signal(s_, h)
+        shutil.rmtree(store_dir, ignore_errors=True)
+
+
+def rendezvous_kwargs():
+    """init_process_group arguments common to the real and the dry run: the self-launcher's private file store when it set one
+    (FOCR_BENCH_INIT), else the launcher's MASTER_ADDR / MASTER_PORT; a SHORT timeout, so that a rank whose peer never arrives
+    fails (and with it the run, see self_launch) instead of waiting for the backend's default of many minutes."""
+    import datetime
+
+    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("FOCR_BENCH_INIT_TIMEOUT", "180")))}
+    if os.environ.get("FOCR_BENCH_INIT"):
+        kw["init_method"] = os.environ["FOCR_BENCH_INIT"]
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+    return kw
+
+
+def injected_failure(rank, stage):
+    """FOCR_BENCH_FAIL_RANK=k[:init|step] (tests/test_bench_launch.py): rank k dies at that stage, so that the launcher's
+    fail-fast path can be exercised without breaking a GPU."""
+    spec = os.environ.get("FOCR_BENCH_FAIL_RANK", "")
+    if not spec:
+        return
+    k, _, st = spec.partition(":")
+    if int(k) == rank and (st or "init") == stage:
+        sys.stderr.write(f"bench.py: injected failure in rank {rank} at stage '{stage}' (FOCR_BENCH_FAIL_RANK)\n")
+        sys.stderr.flush()
+        os._exit(17)
 
 
 def dry_run(args, rank, world, real_stdout):
@@ -114,15 +213,18 @@ def dry_run(args, rank, world, real_stdout):
     import torch
     import torch.distributed as dist
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    injected_failure(rank, "init")
+    if os.environ.get("FOCR_BENCH_DRY_CHATTER"):
+        print(f"dry-launch rank {rank} of {world}", file=sys.stderr, flush=True)
+    dist.init_process_group("gloo", rank=rank, world_size=world, **rendezvous_kwargs())
     P = args.pages_per_gpu
     for _ in range(args.warmup):
         time.sleep(0.001)
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k == args.steps // 2:
+            injected_failure(rank, "step")
         time.sleep(0.001 * (1 + rank))  # ranks differ: the job's time is the slowest rank's
     dt_local = time.perf_counter() - t0
     dist.barrier()
@@ -220,9 +322,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_gather
+    injected_failure(rank, "init")
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
         # RCCL's kernels on a high-priority stream: the collective's few workgroups must not queue behind the thousands of short
         # workgroups of the batches' small kernels for a CU (the scan leaves an eighth of the chip to all of them)
         pg_opts = None
@@ -230,7 +331,7 @@ def main():
             pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         except Exception:  # noqa: BLE001 - an older torch: default priority
             pg_opts = None
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts, **rendezvous_kwargs())
 
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
     global R_W, R_H
@@ -451,6 +552,8 @@ def main():
     timed = True
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if k == args.steps // 2:
+            injected_failure(rank, "step")
         step(k)
     fence(barrier=False)
     dt_own = time.perf_counter() - t0  # this rank's own work done (per_rank_value); the job's time includes the barrier
