@@ -264,11 +264,18 @@ def main():
                          "sharded over the ranks in contiguous blocks (strong scaling): one step = every rank scans its 8192 / N pages "
                          "once, as batches of --pages-per-gpu pages taken from its HBM-resident shard")
     ap.add_argument("--c4-pages", type=int, default=8192, help="total pages of --config c4 (BASELINE configs[3]: 8192)")
+    ap.add_argument("--c3-pages", type=int, default=0,
+                    help="--config c3 as a STREAM (BASELINE configs[2] names 1024 pages): that many different 1200x1600 pages, sharded over the ranks, "
+                         "each rank's block HBM-resident and scanned batch by batch — every batch is new to the size estimates; "
+                         "0 (default) = rescan the resident batches every step")
     ap.add_argument("--mode", choices=["mfma", "direct"], default="mfma")
     ap.add_argument("--threshold", type=float, default=0.8)
     ap.add_argument("--prefilter", choices=["auto", "one", "legacy"], default="auto",
                     help="MFMA prefilter kernel (focr_ctx_set_prefilter): auto = one = threshold planes + scan_mfma2s_kernel; "
                          "legacy = round 1's kernel and int32 threshold tables")
+    ap.add_argument("--tail", choices=["hits", "rows3", "legacy"], default="hits",
+                    help="tail of the MFMA scan (focr_ctx_set_row_tail): hits = verify in flush order, then bucket + sort the hits (default); "
+                         "rows3 = round 3's row tail (candidates bucketed + sorted per row, verified, compacted); legacy = round 2's radix-sort tail")
     ap.add_argument("--legacy-tail", action="store_true",
                     help="round 2's tail (library radix sort of all candidates + verify + compaction) instead of the per-row sort + verify (focr_ctx_set_row_tail(0)), for A/B")
     ap.add_argument("--no-column-drop", action="store_true",
@@ -352,14 +359,16 @@ def main():
         if args.no_column_drop:
             c_.set_column_drop(False)
         if args.legacy_tail:
-            c_.set_row_tail(False)
+            args.tail = "legacy"
+        c_.set_row_tail({"hits": 1, "rows3": 2, "legacy": 0}[args.tail])
     pipe.set_bank(bank)
     scs, pages = [], None
     shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM
-    if args.config == "c4":
+    stream_pages = args.c4_pages if args.config == "c4" else (args.c3_pages if args.config == "c3" else 0)
+    if stream_pages:
         from font_ocr_amd.shard import shard_range
 
-        first, last = shard_range(args.c4_pages, rank, world)
+        first, last = shard_range(stream_pages, rank, world)
         n_mine = last - first
         shard_batches = [(b0, min(P, n_mine - b0)) for b0 in range(0, n_mine, P)]
         host = synth_pages(bank, n_mine, R_W, R_H, first=first)
@@ -399,6 +408,37 @@ def main():
     import threading
 
     jobs = deque()  # tickets of the steps in flight, oldest first
+    # FOCR_BENCH_TRACE=1: host-side time stamps of the submitting thread, the gather thread and the garbage collector (us since
+    # t_trace0), printed to stderr at the end — what does not perturb a timing-dependent stall the way a profiler does
+    trace_on = bool(os.environ.get("FOCR_BENCH_TRACE"))
+    t_trace0 = time.perf_counter()
+    trace_ev = []
+
+    def stamp(who, what, t_a, t_b=None):
+        if trace_on:
+            trace_ev.append((who, what, (t_a - t_trace0) * 1e6, ((t_b if t_b is not None else t_a) - t_trace0) * 1e6))
+
+    # The Python garbage collector stops the SUBMITTING thread: a full (generation 2) collection of this process's heap (torch,
+    # numpy, ctypes: ~10^6 tracked objects) takes tens of milliseconds, during which nothing is submitted and every lane runs
+    # dry.  FOCR_BENCH_GC: "freeze" (default) = collect once, then gc.freeze() before the timed region, so that later collections
+    # only walk the few objects the steps create; "observe" = leave the collector alone; either way the longest pause inside
+    # the timed region is measured and reported (host_gc).
+    import gc
+
+    gc_mode = os.environ.get("FOCR_BENCH_GC", "freeze")
+    gc_t = {}
+    gc_pauses = []  # (generation, start, end), perf_counter seconds
+
+    def on_gc(phase, info):
+        if phase == "start":
+            gc_t[info["generation"]] = time.perf_counter()
+        else:
+            t_e = time.perf_counter()
+            t_s = gc_t.get(info["generation"], t_e)
+            gc_pauses.append((info["generation"], t_s, t_e))
+            stamp("gc", f"generation {info['generation']} collected {info.get('collected', 0)}", t_s, t_e)
+
+    gc.callbacks.append(on_gc)
 
     def run_step(c_):  # one pass of the hot path over one resident batch, synchronously on one context
         c_.scan(args.threshold, 1024, mode)
@@ -438,9 +478,12 @@ def main():
                     t_b = time.perf_counter()
                     while len(pending) > 1:
                         finish_oldest()
+                    t_c = time.perf_counter()
                     gather_dbg[0] += t_b - t_a
-                    gather_dbg[1] += time.perf_counter() - t_b
+                    gather_dbg[1] += t_c - t_b
                     gather_dbg[2] += 1
+                    stamp("gather", f"issue slot {slot}", t_a, t_b)
+                    stamp("gather", "finish previous", t_b, t_c)
             except Exception as e:  # noqa: BLE001 - reported by fence()
                 gathered["err"] = e
                 for ev_ in slot_free:  # never leave the submitter waiting
@@ -471,6 +514,8 @@ def main():
         t_w = time.perf_counter()
         c_ = pipe.wait(t)
         main_dbg[0] += time.perf_counter() - t_w
+        stamp("main", f"wait ticket {t}", t_w, time.perf_counter())
+        t_r = time.perf_counter()
         if timed:
             for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
                 k = kern.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
@@ -483,6 +528,7 @@ def main():
             nbytes = c_.total_chars() * HIT_DTYPE.itemsize
             pipe.release(t)
             gather_q.put((slot, nbytes))
+            stamp("main", f"retire ticket {t} (launches, timings, total_chars, release, queue the gather)", t_r, time.perf_counter())
         else:
             n_chars = c_.total_chars() or n_chars
             pipe.release(t)
@@ -509,6 +555,8 @@ def main():
             main_dbg[1] += t_u - t_s
             main_dbg[2] += time.perf_counter() - t_u
             main_dbg[3] += 1
+            stamp("main", f"slot {slot} free", t_s, t_u)
+            stamp("main", f"submit ticket {t}", t_u, time.perf_counter())
             slot_of[t] = slot
         else:
             t = pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, device_ptr=device_ptr, shape=shape)
@@ -549,6 +597,9 @@ def main():
             flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go = bool(flag.item())
+    if gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
     timed = True
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -560,6 +611,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timed = False
+    gc_in = [(g_, b_ - a_) for g_, a_, b_ in gc_pauses if a_ < t0 + dt and b_ > t0]
+    host_gc = {"mode": gc_mode, "collections_in_timed_region": len(gc_in), "longest_pause_ms": round(max([d_ for _, d_ in gc_in] or [0.0]) * 1e3, 3),
+               "total_pause_ms": round(sum(d_ for _, d_ in gc_in) * 1e3, 3)}
     dt_local = dt_own
     ranks_seen, per_rank = 1, None
     if use_dist:
@@ -570,7 +624,7 @@ def main():
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         ranks_seen = int(seen.item())
 
-    total_px = (args.c4_pages if shard is not None else world * P) * R_W * R_H * args.steps
+    total_px = (stream_pages if shard is not None else world * P) * R_W * R_H * args.steps
     value = total_px / dt / 1e6
     if use_dist:  # every rank's own rate (its pages over its own time)
         my_pages = (n_mine if shard is not None else P) * args.steps
@@ -606,12 +660,17 @@ def main():
 
         def pipe_steps(n):
             tickets = deque()
+            ahead = min(n_ctx, n)  # batch k + n_ctx is announced (its DMA started: focr_pipe_prefetch) right after batch k is submitted
+            for k in range(ahead):
+                pipe.prefetch(pins[k % n_ctx].array)
             for k in range(n):
                 if len(tickets) == n_ctx:
                     t = tickets.popleft()
                     pipe.wait(t)
                     pipe.release(t)
                 tickets.append(pipe.submit(pins[k % n_ctx].array, args.threshold, 1024, mode, True, 0.95, 5))
+                if k + ahead < n:
+                    pipe.prefetch(pins[(k + ahead) % n_ctx].array)
             while tickets:
                 t = tickets.popleft()
                 pipe.wait(t)
@@ -619,7 +678,7 @@ def main():
 
         pipe_steps(2 * n_ctx)
         fence()
-        e2e_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 30))
+        e2e_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 120))  # 0.2 s: fill + drain of the pipeline are 2-3 % of it
         t1 = time.perf_counter()
         pipe_steps(e2e_steps)
         fence()
@@ -642,6 +701,16 @@ def main():
                     k["n"] += 1
         sc.set_scan_cus(scan_cus)
 
+    if trace_on and rank == 0:
+        t_lo, t_hi = (t0 - t_trace0) * 1e6, (t0 + dt - t_trace0) * 1e6
+        print(f"[trace] timed region {t_lo:.0f} .. {t_hi:.0f} us; events longer than 3 ms inside it:", file=sys.stderr)
+        for who, what, a_, b_ in trace_ev:
+            if b_ - a_ > 3000 and a_ < t_hi and b_ > t_lo:
+                print(f"[trace]   {who:7s} {a_:10.0f} .. {b_:10.0f} ({(b_ - a_) / 1e3:7.2f} ms)  {what}", file=sys.stderr)
+        if os.environ.get("FOCR_BENCH_TRACE") == "2":
+            for who, what, a_, b_ in trace_ev:
+                if a_ < t_hi and b_ > t_lo:
+                    print(f"[trace-all] {who:7s} {a_:10.0f} .. {b_:10.0f} ({b_ - a_:8.0f} us)  {what}", file=sys.stderr)
     if use_dist and gather_dbg[2] and rank == 0:
         print(f"[bench] gather thread per gather: issue {gather_dbg[0] / gather_dbg[2] * 1e3:.3f} ms (sizes exchange incl. its host read, staging copies, "
               f"the collective's launch), waiting for the previous one {gather_dbg[1] / gather_dbg[2] * 1e3:.3f} ms; {gather_dbg[2]} gathers; "
@@ -669,6 +738,9 @@ def main():
                         else (f"BASELINE configs[3]: {args.c4_pages} synthetic 608x720 pages sharded over {world} rank(s) in contiguous blocks, each "
                               f"rank's block HBM-resident and scanned in batches of {P}; 380 templates, threshold 0.8, cap 1024, "
                               "+ process_hits(0.95, 5), RCCL gather of the match lists") if args.config == "c4"
+                        else (f"BASELINE configs[2]: {stream_pages} synthetic 1200x1600 pages sharded over {world} rank(s), each rank's block HBM-resident and "
+                              f"scanned in batches of {P} (different pages every batch); 95-glyph bank, --x-bits 2 --y-bits 2 (1520 templates, 16 sub-pixel "
+                              "shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)") if stream_pages
                         else (f"BASELINE configs[2] geometry: batches of {P} synthetic 1200x1600 pages, 95-glyph bank, --x-bits 2 --y-bits 2 "
                               "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
             "pages_per_batch": P,
@@ -679,7 +751,7 @@ def main():
             "scan_mode": args.mode,
             "prefilter": args.prefilter,
             "column_drop": not args.no_column_drop,
-            "tail": "legacy radix sort" if args.legacy_tail else "rows",
+            "tail": {"hits": "hits-first rows", "rows3": "round-3 rows", "legacy": "legacy radix sort"}[args.tail],
             "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
         },
     }
@@ -687,11 +759,13 @@ def main():
         out["e2e_value_incl_h2d"] = round(e2e, 2)
     if e2e_pipe is not None:
         out["e2e_value_incl_h2d_pipelined"] = round(e2e_pipe, 2)
-        out["e2e_note"] = (f"extra untimed leg of {e2e_steps} steps: every batch starts in page-locked host memory and crosses PCIe (one DMA per batch) "
-                           "under the previous batch's scan; `value` is the device-resident rate")
+        out["e2e_note"] = (f"extra untimed leg of {e2e_steps} steps: every batch starts in page-locked host memory and crosses PCIe (one DMA per batch, "
+                           "announced with focr_pipe_prefetch as many batches ahead as there are lanes) under the scans of the batches in flight; "
+                           "`value` is the device-resident rate")
     out["size_estimates"] = {"batches_redone_exact": sum(e["redone"] for e in est), "margin": est[0]["margin"], "largest_page_row": est[0]["row_max"],
                              "note": "every step rescans the same resident batches, so the result-size estimates run at their smallest margin "
                                      "with nothing redone; different batches per step: --config c4"}
+    out["host_gc"] = host_gc
     if per_rank is not None:
         out["per_rank_value"] = per_rank
     if args.noise:
@@ -718,7 +792,9 @@ def main():
             "avg_kernel_ms": round(k["ms"] / k["n"], 4),
             "algorithmic_macs_per_launch": k["alg"],
             "issued_macs_per_launch": k["issued"],
-            "note": "int8 ops (2 per MAC) over true template area x searched windows; peak = dense i8 MFMA; "
+            "frac_issued": round(2.0 * k["issued"] / avg_s / 1e12 / PEAK_I8_MFMA_TOPS, 4),
+            "note": "int8 ops (2 per MAC) over true template area x searched windows; peak = dense i8 MFMA; 'frac_issued' = the MACs the "
+                    "MFMA pipes were actually given (dropped ninth column and blank tiles not counted, padding counted) over the same duration; "
                     "compulsory HBM traffic is 1 B/px (hbm_frac below), the path is MFMA-bound (SURVEY.md 8d)",
             "hbm_frac_compulsory": round(value * 1e6 * 1.0 / 8.0e12, 8),
         }

@@ -258,7 +258,8 @@ struct focr_ctx {
     uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
     uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
     uint32_t row_seg_shift = 0; // log2 of the x-segment width of the buckets (0: not chosen yet for this setup; rows.hip, row_segments)
-    bool rows_enabled = true;   // focr_ctx_set_tail(): false = always the legacy tail (radix sort + verify + compaction)
+    int tail_mode = 1;          // focr_ctx_set_row_tail(): 0 = the legacy tail (radix sort + verify + compaction), 1 = hits-first row tail
+                                // (verify in flush order, hits bucketed + sorted: the default), 2 = round 3's row tail (sort, verify, compact)
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch
     DevBuf post_line_be;

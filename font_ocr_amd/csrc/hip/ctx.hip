@@ -292,7 +292,8 @@ int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
 
 int focr_ctx_set_row_tail(focr_ctx_t *c, int on) {
     if (!c) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: null context");
-    c->rows_enabled = on != 0;
+    if (on < 0 || on > 2) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: 0 (legacy tail), 1 (hits-first row tail, the default) or 2 (round 3's row tail)");
+    c->tail_mode = on;
     c->est_row_max = 0;
     c->est_cand = c->est_hits = 0;  // the next scan runs with exact sizes
     return FOCR_OK;

@@ -63,6 +63,15 @@ struct PipeLane {
     PipeJob job;
     int rc = FOCR_OK;
     bool stop = false;
+    // focr_pipe_prefetch: the NEXT batch's host pages cross PCIe into a staging buffer of the lane's own, on a copy stream,
+    // while the lane still works on its current batch; the lane's ingest then reads them from there
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_prefetch = nullptr, ev_ingest = nullptr;  // copy done / the ingest that read the staging buffer done
+    void *pf_stage = nullptr;
+    size_t pf_stage_bytes = 0;
+    const void *pf_ptr = nullptr;  // host pages announced and on their way (consumed by the submit that brings the same pointer)
+    size_t pf_bytes = 0;
+    bool pf_ingest_recorded = false;  // ev_ingest has been recorded at least once
 };
 
 }  // namespace focr
@@ -82,8 +91,9 @@ struct focr_pipe {
     double now_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
     bool fetch = false;
     std::vector<focr::PipeLane *> lanes;
-    std::mutex mu;  // guards next_ticket
+    std::mutex mu;  // guards next_ticket, announced
     uint64_t next_ticket = 1;
+    uint64_t announced = 0;  // focr_pipe_prefetch calls not yet consumed by their focr_pipe_submit
 };
 
 namespace focr {
@@ -110,9 +120,26 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
         int rc = FOCR_OK;
         if (job.pages) {
             rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
-            if (rc == FOCR_OK)
+            bool prefetched = false;
+            {
+                std::lock_guard<std::mutex> lk(L->mu);
+                prefetched = !job.on_device && L->pf_ptr == job.pages && L->pf_bytes == job.n_pages * job.r_w * job.r_h;
+            }
+            if (rc == FOCR_OK && prefetched) {  // the pages are already in the lane's staging buffer (or on their way): no copy on this stream
+                hipError_t e = hipStreamWaitEvent(c->stream, L->ev_prefetch, 0);
+                if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: prefetch wait failed: ") + hipGetErrorString(e));
+                if (rc == FOCR_OK) rc = focr_pages_upload_device(c, 0, job.n_pages, L->pf_stage, job.invert);
+                if (rc == FOCR_OK && hipEventRecord(L->ev_ingest, c->stream) != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, "focr_pipe: hipEventRecord failed");
+                {
+                    std::lock_guard<std::mutex> lk(L->mu);
+                    L->pf_ptr = nullptr;  // the staging buffer may take the next announcement (behind ev_ingest on the device)
+                    L->pf_ingest_recorded = true;
+                }
+                L->cv.notify_all();
+            } else if (rc == FOCR_OK) {
                 rc = job.on_device ? focr_pages_upload_device(c, 0, job.n_pages, job.pages, job.invert)
                                    : focr_pages_upload(c, 0, job.n_pages, (const uint8_t *)job.pages, job.invert);
+            }
         }
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
         P->gate.skip(ticket);  // no-op when the scan took its turn; a batch that ended before must not hold up the later tickets
@@ -221,6 +248,13 @@ void focr_pipe_destroy(focr_pipe_t *p) {
         L->cv.notify_all();
         if (L->worker.joinable()) L->worker.join();
         (void)hipSetDevice(L->ctx->device);
+        if (L->copy_stream) {
+            (void)hipStreamSynchronize(L->copy_stream);
+            (void)hipStreamDestroy(L->copy_stream);
+        }
+        if (L->ev_prefetch) (void)hipEventDestroy(L->ev_prefetch);
+        if (L->ev_ingest) (void)hipEventDestroy(L->ev_ingest);
+        if (L->pf_stage) (void)hipFree(L->pf_stage);
         for (PinBuf *b : {&L->h_counts, &L->h_page_off, &L->h_line_off, &L->h_chars}) b->release();
         focr_ctx_destroy(L->ctx);
         delete L;
@@ -255,6 +289,13 @@ int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, siz
     uint64_t t;
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        if (p->announced) {  // batches announced with focr_pipe_prefetch are submitted in the order they were announced
+            PipeLane *Ln = p->lanes[(p->next_ticket - 1) % p->lanes.size()];
+            std::lock_guard<std::mutex> lk2(Ln->mu);
+            if (Ln->pf_ptr != pages || pages_on_device)
+                return fail(nullptr, FOCR_ERR_STATE, "focr_pipe_submit: another batch was announced with focr_pipe_prefetch for this ticket");
+            p->announced--;
+        }
         t = p->next_ticket++;
     }
     PipeLane *L = p->lanes[(t - 1) % p->lanes.size()];
@@ -280,6 +321,39 @@ int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, siz
     }
     L->cv.notify_all();
     *ticket = t;
+    return FOCR_OK;
+}
+
+int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t r_w, size_t r_h) {
+    if (!p || !pages || !n_pages || !r_w || !r_h) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_prefetch: bad arguments");
+    std::lock_guard<std::mutex> plk(p->mu);  // announcements and submits are serialised
+    if (p->announced >= p->lanes.size()) return fail(nullptr, FOCR_ERR_STATE, "focr_pipe_prefetch: every lane already holds an announced batch");
+    PipeLane *L = p->lanes[(p->next_ticket + p->announced - 1) % p->lanes.size()];
+    focr_ctx *c = L->ctx;
+    const size_t bytes = n_pages * r_w * r_h;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    std::unique_lock<std::mutex> lk(L->mu);
+    // the lane's previous announced batch has been ingested out of the staging buffer (queued, at least: ev_ingest orders the rest)
+    L->cv.wait(lk, [&] { return L->pf_ptr == nullptr; });
+    if (!L->copy_stream) {
+        FOCR_HIP(c, hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
+        FOCR_HIP(c, hipEventCreateWithFlags(&L->ev_prefetch, hipEventDisableTiming));
+        FOCR_HIP(c, hipEventCreateWithFlags(&L->ev_ingest, hipEventDisableTiming));
+    }
+    if (L->pf_stage_bytes < bytes) {
+        if (L->pf_ingest_recorded) FOCR_HIP(c, hipEventSynchronize(L->ev_ingest));  // nobody reads the old buffer any more
+        if (L->pf_stage) (void)hipFree(L->pf_stage);
+        L->pf_stage = nullptr;
+        L->pf_stage_bytes = 0;
+        if (hipMalloc(&L->pf_stage, bytes) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "focr_pipe_prefetch: hipMalloc failed");
+        L->pf_stage_bytes = bytes;
+    }
+    if (L->pf_ingest_recorded) FOCR_HIP(c, hipStreamWaitEvent(L->copy_stream, L->ev_ingest, 0));  // the previous batch's ingest has read the buffer
+    FOCR_HIP(c, hipMemcpyAsync(L->pf_stage, pages, bytes, hipMemcpyHostToDevice, L->copy_stream));
+    FOCR_HIP(c, hipEventRecord(L->ev_prefetch, L->copy_stream));
+    L->pf_ptr = pages;
+    L->pf_bytes = bytes;
+    p->announced++;
     return FOCR_OK;
 }
 

@@ -148,10 +148,14 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__rest
 //                 (batch redone through the legacy tail).
 constexpr uint32_t XBINS = 1024;
 constexpr unsigned VERIFY_THREADS = 1024;
-template <int CAP, int WAVES, bool LIST>
+//   PAY: every key carries a float (the hits-first tail sorts verified hits with their similarities): loaded with the keys,
+//        stored at the key's new place; `limit` = entries the arrays hold (a bucket that would reach past it is left alone: the
+//        hit count exceeded its estimate and the batch is redone, record_scan_sizes).
+template <int CAP, int WAVES, bool LIST, bool PAY>
 __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
                                                               uint64_t *__restrict__ bucket, uint32_t sub_bits, uint32_t bt, uint32_t seg_mask, uint32_t xs, uint32_t n_bins,
-                                                              uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word) {
+                                                              uint32_t *__restrict__ big, unsigned long long *__restrict__ flags_word, float *__restrict__ pay,
+                                                              unsigned long long limit) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sort_lds[];  // per wave: XBINS + 1 bin starts, CAP placed sub-keys
     constexpr int K = CAP / 64;  // sub-keys per lane, in registers
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -175,7 +179,9 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
             n2 = fill[r2];
             b2 = base[r2];
         }
-        if (n > (uint32_t)CAP) {
+        if (PAY && (unsigned long long)b + n > limit) {
+            // past the arrays' end (estimated sizes too small): nothing to sort, the batch is redone
+        } else if (n > (uint32_t)CAP) {
             if (lane == 0) {
                 if (LIST) {
                     atomicOr(flags_word, 2ull);
@@ -188,22 +194,32 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
             // — no LDS, no bins; keys are unique, so the rank is the key's place
             uint64_t *row = bucket + b;
             const uint64_t key = row[(uint32_t)lane < n ? lane : n - 1];
+            float pv = 0.f;
+            if (PAY) pv = pay[b + ((uint32_t)lane < n ? lane : n - 1)];
             const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) {  // j is wave-uniform: v_readlane
                 const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, (int)j);
                 rank += other < key;
             }
-            if ((uint32_t)lane < n) row[rank] = key;
+            if ((uint32_t)lane < n) {
+                row[rank] = key;
+                if (PAY) pay[b + rank] = pv;
+            }
         } else if (n >= 2) {
             uint64_t *row = bucket + b;
             uint32_t sub[K], slot[K];
             uint64_t key[K];
+            float pv[PAY ? K : 1];
 #pragma unroll
             for (int k = 0; k < K; k++) {  // all of the row's loads in flight at once: nothing but loads in this loop
                 const uint32_t j = (uint32_t)lane + 64u * k;
                 key[k] = 0;
-                if (64u * k < n) key[k] = row[j < n ? j : n - 1];  // wave-uniform branch; lanes past the end re-read the last key
+                if (PAY) pv[k] = 0.f;
+                if (64u * k < n) {  // wave-uniform branch; lanes past the end re-read the last key
+                    key[k] = row[j < n ? j : n - 1];
+                    if (PAY) pv[k] = pay[b + (j < n ? j : n - 1)];
+                }
             }
 #pragma unroll
             for (int k = 0; k < K; k++) sub[k] = (uint32_t)(key[k] & sub_mask);
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
                     uint32_t rank = 0;
                     for (uint32_t i = lo; i < hi; i++) rank += out[i] < e;
                     row[lo + rank] = high | e;
+                    if (PAY) pay[b + lo + rank] = pv[k];
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next row reuses the LDS buffers
         }
@@ -333,6 +350,91 @@ __global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// The hits-first tail (round 4).  The row tail above sorts every CANDIDATE before it is verified, although four in ten are
+// thrown away by the verify (BASELINE configs[1]: 4.53 M candidates, 2.72 M hits per batch; configs[2]: 48.9 M / 26.0 M), and
+// moves them three times (scatter, sort, compaction).  The verify does not need sorted input — it needs neighbouring lanes on
+// neighbouring windows, and the scan kernels' flush order gives that already: the 64 keys of a flush come from one item, i.e.
+// 64 adjacent windows of one page row.  So:
+//
+//   verify_list       the reference arithmetic on every candidate in FLUSH order; a hit takes the next free slot of its
+//                     bucket (one returning atomic per distinct bucket among the wave's hits) — similarity + slot in place
+//   row_prefix        exclusive prefix of the buckets' hit counts -> the dense position of every bucket, hit total, largest bucket
+//   hit_scatter       hit -> hbase[bucket] + slot: the dense (key, similarity) arrays in bucket order, arbitrary inside a bucket
+//   row_sort<PAY>     one wave per bucket, keys with their similarities, in place -> (page, y, x, t) order: what order.hip takes over
+//
+// Four launches (+ the second capacity class of the sort) instead of seven, no counting in the scan kernels' flush path, and
+// every pass behind the verify touches hits only.
+template <int MODE>
+__global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_list_kernel(
+    const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
+    float *__restrict__ sims, uint32_t *__restrict__ slots, uint32_t *__restrict__ row_hits) {
+    // LDS: [template records: n_templates x 32 B][template rows, 16 B (MODE 1) or 12 B (MODE 2) each]
+    extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    constexpr bool LDS = MODE == 1;
+    VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
+    v4i *needle_lds = verify_lds + 2 * va.n_templates;
+    uint32_t *needle12 = reinterpret_cast<uint32_t *>(needle_lds);
+    for (uint32_t i = threadIdx.x; i < 2 * va.n_templates; i += blockDim.x) verify_lds[i] = reinterpret_cast<const v4i *>(va.vmeta)[i];
+    if (MODE == 1)
+        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
+    if (MODE == 2)
+        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) {
+            const v4i r = va.needles16[i];
+            needle12[3 * i] = (uint32_t)r[0], needle12[3 * i + 1] = (uint32_t)r[1], needle12[3 * i + 2] = (uint32_t)r[2];
+        }
+    __syncthreads();
+    const unsigned long long n = min(*n_cand_p, cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    uint64_t key_next = first + lane < n ? cand[first + lane] : 0;  // the next step's key is loaded a step ahead
+    for (unsigned long long i0 = first; i0 < n; i0 += stride) {  // wave-uniform trip count
+        const unsigned long long i = i0 + lane;
+        const bool valid = i < n;
+        const uint64_t key = key_next;
+        if (i + stride < n) key_next = cand[i + stride];
+        float sim = 0.f;
+        const bool emit = valid && (MODE == 2 ? verify_candidate_narrow(key, va, needle12, meta, &sim) : verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim));
+        // a hit's slot inside its bucket: the wave's 64 candidates come from a handful of page rows
+        const uint32_t r = emit ? row_of_key(key, rows) : 0xffffffffu;
+        uint32_t slot = 0xffffffffu;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(emit);
+        while (todo) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
+            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
+            uint32_t start = 0;
+            if (lane == (int)__builtin_ctzll(peers)) start = atomicAdd(row_hits + r0, (uint32_t)__builtin_popcountll(peers));
+            start = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)__builtin_ctzll(peers));
+            if (r == r0) slot = start + __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            todo &= ~peers;
+        }
+        if (valid) {
+            sims[i] = sim;
+            slots[i] = slot;
+        }
+    }
+}
+
+// hit -> its dense place: hbase[bucket] + slot (no atomics: the slots were handed out by the verify)
+__global__ __launch_bounds__(256) void hit_scatter_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap,
+                                                          const RowHist rows, const uint32_t *__restrict__ hbase, const float *__restrict__ sims,
+                                                          const uint32_t *__restrict__ slots, uint64_t *__restrict__ hkeys, float *__restrict__ hsims,
+                                                          unsigned long long hit_cap) {
+    const unsigned long long n = min(*n_cand_p, cap);
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = slots[i];
+        if (slot == 0xffffffffu) continue;
+        const uint64_t key = cand[i];
+        const unsigned long long pos = (unsigned long long)hbase[row_of_key(key, rows)] + slot;
+        if (pos < hit_cap) {  // estimated sizes: a hit count above its bound is flagged by record_scan_sizes and the batch redone
+            hkeys[pos] = key;
+            hsims[pos] = sims[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 
 // x-segments per page row: a bucket should hold what one wave sorts in registers (<= 1024 candidates; up to 4096 go through
@@ -357,11 +459,27 @@ static size_t row_buckets(const focr_ctx *c) {
 }
 
 bool rows_applicable(const focr_ctx *c) {
-    if (!c->rows_enabled) return false;
+    if (c->tail_mode == 0) return false;
     for (const SizeClass &sc : c->classes)
         if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per bucket
     static_assert(sizeof(VerifyMeta) == 32, "VerifyMeta is staged in LDS as two 16-byte words per template");
     return row_buckets(c) <= ((size_t)1 << 22) && c->fmt.bp + c->fmt.by <= 32 && c->n_templates <= 4096;  // 4096 x 32 B of template records in the verify's LDS
+}
+
+// hits-first tail, before the scan kernels: zeroed hit counters per bucket; the scan kernels count nothing (row_hist.cnt = null)
+int rows2_begin(focr_ctx *c, ClearList &clear) {
+    const size_t n_rows = row_buckets(c);
+    const size_t padded = (n_rows + 1 + 3) / 4 * 4 + 4;  // row_prefix_kernel moves 16 bytes at a time
+    uint32_t *hits = (uint32_t *)c->rows_hits.ensure(c, padded * 4);
+    if (!hits || !c->rows_hbase.ensure(c, padded * 4)) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4 + 8);  // [0]: length of the list of large buckets
+    if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    if (!clear.add(hits, padded * 4)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
+    if (!clear.add(big, 8)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
+    uint32_t seg_shift, n_seg;
+    row_segments(c, &seg_shift, &n_seg);
+    c->row_hist = RowHist{nullptr, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0, c->fmt.bt, c->fmt.bx, seg_shift, n_seg};
+    return FOCR_OK;
 }
 
 // before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
@@ -430,17 +548,17 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
         while ((seg_w >> xs) > XBINS) xs++;
         const uint32_t n_bins = seg_w >> xs;
         uint32_t *big = (uint32_t *)c->rows_big.p;  // allocated and zeroed in rows_begin
-        auto k1 = row_sort_kernel<1024, 4, false>;
-        auto k2 = row_sort_kernel<4096, 1, true>;
+        auto k1 = row_sort_kernel<1024, 4, false, false>;
+        auto k2 = row_sort_kernel<4096, 1, true, false>;
         const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
         hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
-                           seg_w - 1, xs, n_bins, big, flags_word);
+                           seg_w - 1, xs, n_bins, big, flags_word, (float *)nullptr, ~0ull);
         FOCR_HIP(c, hipGetLastError());
         // the buckets above 1 024 keys (the list `big`): one wave each over the whole chip where the last scan of this setup had any
         // (or the exact count says so), else ONE wave — it still sorts whatever turns up, but a launch of `cus` single-wave
         // workgroups that find an empty list cost 60 us of a lane's time in flight
         hipLaunchKernelGGL(k2, dim3(big_expected ? cus : 1u), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
-                           big, flags_word);
+                           big, flags_word, (float *)nullptr, ~0ull);
         FOCR_HIP(c, hipGetLastError());
     }
     if (ub_c) {
@@ -483,6 +601,94 @@ int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, siz
                            (unsigned long long)c->hit_capacity);
         FOCR_HIP(c, hipGetLastError());
     }
+    return FOCR_OK;
+}
+
+
+// The verify operand's place for this bank: 2 = 12-byte rows in LDS, two workgroups per CU; 1 = 16-byte rows in LDS; 0 = global memory
+static int verify_mode(const focr_ctx *c, size_t *lds, uint32_t *rows_out) {
+    size_t all_rows = 0;
+    uint32_t max_w = 0;
+    for (const TemplateConst &tc : c->h_tconst) {
+        all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
+        max_w = std::max<uint32_t>(max_w, tc.n_w);
+    }
+    const size_t meta_bytes = c->n_templates * sizeof(VerifyMeta);  // <= 4096 templates here: 128 KiB at most
+    const bool narrow = max_w <= 12 && meta_bytes + all_rows * 12 <= ((size_t)80 << 10) - 256;
+    const bool in_lds = meta_bytes + all_rows * 16 <= ((size_t)144 << 10);
+    *lds = meta_bytes + (narrow ? all_rows * 12 : in_lds ? all_rows * 16 : 0);
+    *rows_out = (uint32_t)all_rows;
+    return narrow ? 2 : in_lds ? 1 : 0;
+}
+
+// hits-first tail, phase 1 (right behind the scan kernels): exact verify of the candidate list in flush order, hit counts and
+// slots per bucket, prefix -> d_res[6] = hits, d_res[5] = the largest bucket.  Records ev[3] behind the verify.
+int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c) {
+    const uint32_t n_rows = (uint32_t)row_buckets(c);
+    float *csims = (float *)c->scan_pos.ensure(c, (ub_c + 1) * 4);
+    uint32_t *cslots = (uint32_t *)c->scan_flags.ensure(c, (ub_c + 1) * 4);
+    if (!csims || !cslots) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
+    const unsigned cus = c->n_cus;
+    uint32_t *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
+    if (ub_c) {
+        const VerifyArgs va = verify_args(c, thr_d);
+        size_t lds;
+        uint32_t all_rows;
+        const int mode = verify_mode(c, &lds, &all_rows);
+        const unsigned per_cu = mode == 2 ? 2u : (mode == 0 && c->n_templates * sizeof(VerifyMeta) <= ((size_t)64 << 10) ? 2u : 1u);
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus * per_cu));
+#define FOCR_VERIFY_LIST(M)                                                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_list_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    hipLaunchKernelGGL(verify_list_kernel<M>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
+                       M == 0 ? 0u : all_rows, c->row_hist, csims, cslots, hits)
+        if (mode == 2) {
+            FOCR_VERIFY_LIST(2);
+        } else if (mode == 1) {
+            FOCR_VERIFY_LIST(1);
+        } else {
+            FOCR_VERIFY_LIST(0);
+        }
+#undef FOCR_VERIFY_LIST
+        FOCR_HIP(c, hipGetLastError());
+    }
+    FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6, c->d_res + 5);
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+// hits-first tail, phase 2: hits to their buckets, every bucket sorted with its similarities -> the dense sorted hits in
+// d_hit_keys / d_hit_sims_alt (their number: d_res[6]).  ub_h: bound on the hits (exact sizes: the count itself).
+int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, size_t ub_h, bool big_expected, bool sort) {
+    const uint32_t n_rows = (uint32_t)row_buckets(c);
+    int rc;
+    if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_h + 1)))) return rc;
+    const unsigned cus = c->n_cus;
+    const uint32_t *hits = (const uint32_t *)c->rows_hits.p, *hbase = (const uint32_t *)c->rows_hbase.p;
+    if (ub_c) {
+        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16);
+        hipLaunchKernelGGL(hit_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, c->row_hist, hbase,
+                           (const float *)c->scan_pos.p, (const uint32_t *)c->scan_flags.p, c->d_hit_keys, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+        FOCR_HIP(c, hipGetLastError());
+    }
+    if (!sort) return FOCR_OK;  // a bucket beyond the row sort's capacity (exact sizes know): the caller sorts the placed hits with the library sort
+    unsigned long long *flags_word = (unsigned long long *)(c->d_res + 4);
+    const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
+    const uint32_t seg_w = 1u << c->row_hist.seg_shift;
+    uint32_t xs = 0;
+    while ((seg_w >> xs) > XBINS) xs++;
+    const uint32_t n_bins = seg_w >> xs;
+    uint32_t *big = (uint32_t *)c->rows_big.p;  // allocated and zeroed in rows2_begin
+    auto k1 = row_sort_kernel<1024, 4, false, true>;
+    auto k2 = row_sort_kernel<4096, 1, true, true>;
+    const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
+    hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins, big,
+                       flags_word, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+    FOCR_HIP(c, hipGetLastError());
+    // buckets above 1 024 hits: see rows_tail (one wave unless such a bucket is expected)
+    hipLaunchKernelGGL(k2, dim3(big_expected ? cus : 1u), dim3(64), lds2, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
+                       big, flags_word, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+    FOCR_HIP(c, hipGetLastError());
     return FOCR_OK;
 }
 

@@ -56,6 +56,10 @@ int rows_begin(focr_ctx *c, ClearList &clear);
 int rows_prefix(focr_ctx *c);
 uint32_t rows_capacity_for(uint64_t row_max);
 int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class, bool big_expected);
+int rows2_begin(focr_ctx *c, ClearList &clear);  // the hits-first tail (rows.hip): verify in flush order, then only hits are placed and sorted
+int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c);
+int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, size_t ub_h, bool big_expected, bool sort);
+int sort_pairs_u64_f32(focr_ctx *c, uint64_t *&keys, uint64_t *&keys_alt, float *&vals, float *&vals_alt, size_t n, unsigned end_bit);
 
 
 // ---------------------------------------------------------------------------------------------
@@ -661,7 +665,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             use_rows = c->est_row_max != 0 && row_cap != 0;
         }
         c->row_hist = RowHist{};
-        if (use_rows && (rc = rows_begin(c, clear))) return rc;
+        const bool hits_first = use_rows && c->tail_mode == 1;  // verify in flush order, only hits are bucketed and sorted (rows.hip)
+        if (use_rows && (rc = hits_first ? rows2_begin(c, clear) : rows_begin(c, clear))) return rc;
         // legacy tail, estimated sizes: unused candidate slots hold the largest key so that the radix sort leaves them at the end
         if (c->estimated && !use_rows) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
@@ -869,15 +874,15 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipMemcpyAsync(c->h_live, c->d_counter + 8, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         const unsigned long long *n_cand_p = (const unsigned long long *)c->d_counter + 1;
         size_t ub_c = c->ub_cand;
-        if (use_rows && !nothing && (rc = rows_prefix(c))) return rc;
+        if (use_rows && !hits_first && !nothing && (rc = rows_prefix(c))) return rc;
         if (nothing) use_rows = false;
         bool big_expected = c->est_row_max > 1024;  // buckets above the row sort's first capacity class (rows_tail)
         if (!c->estimated) {
             unsigned long long n_cand = 0, row_max = 0;
             FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
-            if (use_rows) FOCR_HIP(c, hipMemcpyAsync(&row_max, c->d_res + 5, 8, hipMemcpyDeviceToHost, c->stream));
+            if (use_rows && !hits_first) FOCR_HIP(c, hipMemcpyAsync(&row_max, c->d_res + 5, 8, hipMemcpyDeviceToHost, c->stream));
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
-            if (use_rows) {
+            if (use_rows && !hits_first) {
                 row_cap = rows_capacity_for(row_max);
                 use_rows = row_cap != 0;  // a row beyond the largest capacity: legacy tail for this scan
                 big_expected = row_max > 1024;
@@ -888,6 +893,26 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 continue;
             }
             ub_c = (size_t)n_cand;
+        }
+        if (use_rows && hits_first) {
+            // 3a'. hits-first row path: verify the candidates where they lie, then bucket + sort the hits only (rows.hip)
+            if ((rc = rows2_verify(c, thr_d, n_cand_p, ub_c))) return rc;
+            size_t ub_h = std::min(ub_c, c->est_hits);
+            bool sort_rows = true;
+            if (!c->estimated) {  // exact number of hits and the largest bucket
+                uint64_t hits = 0, row_max = 0;
+                FOCR_HIP(c, hipMemcpyAsync(&hits, c->d_res + 6, 8, hipMemcpyDeviceToHost, c->stream));
+                FOCR_HIP(c, hipMemcpyAsync(&row_max, c->d_res + 5, 8, hipMemcpyDeviceToHost, c->stream));
+                FOCR_HIP(c, hipStreamSynchronize(c->stream));
+                ub_h = (size_t)hits;
+                big_expected = row_max > 1024;
+                sort_rows = rows_capacity_for(row_max) != 0;  // a bucket beyond the sort's largest capacity: library sort of the placed hits
+                row_cap = sort_rows ? rows_capacity_for(row_max) : 0;
+            }
+            c->row_cap = row_cap;
+            if ((rc = rows2_place(c, n_cand_p, ub_c, ub_h, big_expected, sort_rows))) return rc;
+            if (!sort_rows && (rc = sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims_alt, c->d_hit_sims, ub_h, c->fmt.bits()))) return rc;
+            return order_sorted_hits(c, c->d_hit_keys, c->d_hit_sims_alt, c->d_res + 6, ub_h, n_cand_p, ub_c);
         }
         c->row_cap = use_rows ? row_cap : 0;
         if (use_rows) {

@@ -175,9 +175,9 @@ class Scanner:
         self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
 
     def set_row_tail(self, on):
-        """focr_ctx_set_row_tail: per-row sort + verify of the candidates (default) or the legacy radix-sort tail; results
-        never change."""
-        self._ck(self._lib.focr_ctx_set_row_tail(self._h, int(bool(on))))
+        """focr_ctx_set_row_tail: True / 1 = hits-first row tail (default), 2 = round 3's row tail (sort, verify, compact),
+        False / 0 = the legacy radix-sort tail; results never change."""
+        self._ck(self._lib.focr_ctx_set_row_tail(self._h, int(on)))
 
     def set_column_drop(self, on):
         """focr_ctx_set_column_drop: bound the last column of 9- / 13-wide classes instead of multiplying it (default on);
@@ -339,10 +339,25 @@ class Pipeline:
             raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
         if luma is not None:
             self._keep[t.value] = luma
+            if getattr(self, "_announced", None):
+                self._announced.pop(0)
         lane = self.scanners[(t.value - 1) % len(self.scanners)]
         if n:
             lane.n_pages, lane.r_w, lane.r_h = n, r_w, r_h
         return t.value
+
+    def prefetch(self, luma):
+        """focr_pipe_prefetch: announce the host pages (n, r_h, r_w) uint8 of the batch that will be submitted after everything
+        announced or submitted so far, and start their copy to the device now (page-locked memory: PinnedPages).  The matching
+        submit must bring the same array."""
+        if luma.dtype != np.uint8 or not luma.flags["C_CONTIGUOUS"] or luma.ndim != 3:
+            raise ValueError("prefetch: a C-contiguous (n, r_h, r_w) uint8 array")
+        n, r_h, r_w = luma.shape
+        rc = self._lib.focr_pipe_prefetch(self._h, _ptr(luma), n, r_w, r_h)
+        if rc != 0:
+            raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
+        self._announced = getattr(self, "_announced", [])
+        self._announced.append(luma)  # kept alive until its submit takes over
 
     def wait(self, ticket):
         """Blocks until the batch is done; returns the Scanner whose getters (matches, lines, counts...) see it."""

@@ -240,11 +240,13 @@ int focr_ctx_set_prefilter(focr_ctx_t *ctx, int mode);
  * the next focr_bank_upload. */
 int focr_ctx_set_column_drop(focr_ctx_t *ctx, int on);
 
-/* Tail of the MFMA scan (default on = the row path, rows.hip): candidates are bucketed by page row, sorted and verified
- * per row in LDS.  Off = the legacy tail (library radix sort of all candidates, verify, flag scan, compaction), which
- * also serves batches the row path does not cover (a page row with more than 4096 candidates, banks with templates
- * taller than 32 px).  Results are identical either way. */
-int focr_ctx_set_row_tail(focr_ctx_t *ctx, int on);
+/* Tail of the MFMA scan (rows.hip).  1 (default) = the hits-first row path: the candidates are verified where the scan kernels
+ * left them (flush order: neighbouring lanes, neighbouring windows), then only the HITS are bucketed by page row and sorted
+ * per bucket with their similarities.  2 = round 3's row path (candidates bucketed and sorted per row, then verified, then
+ * compacted), kept for A/B.  0 = the legacy tail (library radix sort of all candidates, verify, flag scan, compaction), which
+ * also serves batches the row paths do not cover (banks with templates taller than 32 px or more than 4096 templates).
+ * Results are identical in every mode. */
+int focr_ctx_set_row_tail(focr_ctx_t *ctx, int mode);
 
 /* Result sizes.  Every phase behind the scan kernel takes its element count from device memory.  A scan of the same
  * setup as the context's previous one (same bank, batch geometry, threshold, cap) bounds its buffers by the previous
@@ -296,6 +298,16 @@ int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, 
                      size_t r_h, int invert, float threshold, uint32_t cap, int mode, int process_hits,
                      float anchor_threshold, int32_t overlap, void *chars_out, size_t chars_out_bytes,
                      uint64_t *ticket);
+/* Announce the host pages of a batch that will be submitted AFTER every batch announced or submitted so far, and start
+ * their copy to the device now: one DMA on a copy stream of the lane the batch will run on, into a staging buffer of that
+ * lane's own — under the scans of the batches in flight, instead of at the head of the batch's own chain of kernels (a lane's
+ * chain is what decides whether the scans of consecutive batches follow each other without a gap: DESIGN.md section 5).
+ * The matching focr_pipe_submit must bring the same pointer and geometry; announced batches must be submitted in the order
+ * they were announced (FOCR_ERR_STATE otherwise).  At most one announcement per lane: with n contexts, announce batch
+ * b + n right after submitting batch b.  Page-locked memory (focr_host_alloc) makes the copy asynchronous.  The pages must
+ * stay valid and unchanged until that batch's focr_pipe_wait returns.  Optional: a batch that was not announced is
+ * uploaded by its lane as before (src/ncc.rs:575, 880-892: the reference decodes and converts inside the page loop). */
+int focr_pipe_prefetch(focr_pipe_t *pipe, const void *pages, size_t n_pages, size_t r_w, size_t r_h);
 /* Results on the host without touching the context from the consumer's thread: with fetch on, every lane copies its
  * batch's per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory
  * of its own before the batch completes; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out

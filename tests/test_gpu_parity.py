@@ -243,14 +243,14 @@ def test_full_size_c2_properties(scanner, bank_x2):
         assert res[SCAN_DIRECT][2].tobytes() == res[mode][2].tobytes()
     # the price of the bound: more candidates for verify to reject, the same hits (about 1.2 x)
     assert cand[FULL] < cand[MFMA1] < 1.5 * cand[FULL], cand
-    # the tail: per-row sort + verify (rows.hip, the default: the scans above) against the legacy radix-sort tail
-    scanner.set_row_tail(False)
-    scanner.scan(0.8, 1024, MFMA1)
-    assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes()
-    scanner.set_row_tail(True)
-    scanner.scan(0.8, 1024, MFMA1)  # first scan after the switch: exact sizes
-    scanner.scan(0.8, 1024, MFMA1)  # estimated sizes on the row path
-    assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes()
+    # the tail: the hits-first row path (rows.hip, the default: the scans above) against the legacy radix-sort tail and round 3's
+    # row path (sort, verify, compact), each with exact and with estimated sizes
+    for tail in (0, 2, 1):
+        scanner.set_row_tail(tail)
+        scanner.scan(0.8, 1024, MFMA1)  # first scan after the switch: exact sizes
+        assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes(), tail
+        scanner.scan(0.8, 1024, MFMA1)  # estimated sizes
+        assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes(), tail
     res[SCAN_MFMA] = res[FULL]
     scanner.process_hits(0.95, 5)
     lines = scanner.lines()
@@ -555,7 +555,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
         thr = float(rng.choice([-0.5, 0.1, 0.4, 0.8, 0.97]))
         cap = int(rng.choice([1, 2, 37, 1024]))
         scanner.set_column_drop(True)
-        scanner.set_row_tail(it % 3 != 2)  # every third case through the legacy tail
+        scanner.set_row_tail((1, 2, 0)[it % 3])  # hits-first row tail, round 3's row tail, the legacy tail in turn
         scanner.set_bank(bank)
         scanner.set_pages(pages)
         want = _oracle_lists(pages, bank, thr, cap)
@@ -752,6 +752,56 @@ def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
             pipe.release(t)  # already released
     finally:
         pipe.close()
+
+
+def test_pipeline_prefetch_matches_oracle(bank_x2):
+    """Round 4: batches announced ahead with focr_pipe_prefetch (their DMA runs on a copy stream while the lane still works on its
+    previous batch) — same lists as the oracle, announcements must be submitted in order, and a batch that was not announced is
+    still uploaded by its lane."""
+    from font_ocr_amd.searcher import FocrError, PinnedPages, Pipeline
+
+    n_batches, n_lanes = 8, 3
+    pins = []
+    for b in range(n_batches):
+        pin = PinnedPages(2, 96, 288)
+        for p in range(2):
+            pin.array[p] = synth_page(bank_x2, SYNTH_SEED_BASE + 1300 + 2 * b + p, 288, 96)
+        pins.append(pin)
+    want = [_oracle_lists(pin.array, bank_x2, 0.8, 1024) for pin in pins]
+    pipe = Pipeline(0, n_lanes)
+    try:
+        pipe.set_bank(bank_x2)
+        for b in range(n_lanes):
+            pipe.prefetch(pins[b].array)
+        with pytest.raises(FocrError):
+            pipe.prefetch(pins[n_lanes].array)  # every lane already holds an announcement
+        with pytest.raises(FocrError):
+            pipe.submit(pins[1].array, 0.8)  # batch 0 was announced for this ticket
+        tickets = []
+        for b in range(n_batches):
+            if len(tickets) >= n_lanes:
+                t = tickets[b - n_lanes]
+                sc = pipe.wait(t)
+                offsets, m = sc.matches()
+                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - n_lanes], f"batch {b - n_lanes}")
+                pipe.release(t)
+            tickets.append(pipe.submit(pins[b].array, 0.8))
+            if b + n_lanes < n_batches:
+                pipe.prefetch(pins[b + n_lanes].array)
+        for b in range(n_batches - n_lanes, n_batches):
+            sc = pipe.wait(tickets[b])
+            offsets, m = sc.matches()
+            _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"batch {b}")
+            pipe.release(tickets[b])
+        t = pipe.submit(pins[0].array, 0.8)  # not announced: the lane uploads it itself
+        sc = pipe.wait(t)
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[0], "batch that was not announced")
+        pipe.release(t)
+    finally:
+        pipe.close()
+        for pin in pins:
+            pin.close()
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -22,6 +22,7 @@ ap.add_argument("--in-flight", type=int, default=3)
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--pages", type=int, default=128)
 ap.add_argument("--pins", type=int, default=0)
+ap.add_argument("--no-prefetch", action="store_true", help="round 3's form: every lane uploads its batch at the head of its own chain")
 a = ap.parse_args()
 R_W, R_H, P = 608, 720, a.pages
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -39,12 +40,17 @@ for j in range(n_pins):
 
 def run(n, resident):
     tickets = deque()
+    ahead = 0 if (resident or a.no_prefetch) else min(a.in_flight, n)  # batches announced ahead of their submit (focr_pipe_prefetch)
+    for k in range(ahead):
+        pipe.prefetch(pins[k % n_pins].array)
     for k in range(n):
         if len(tickets) == a.in_flight:
             t = tickets.popleft()
             pipe.wait(t)
             pipe.release(t)
         tickets.append(pipe.submit(None if resident else pins[k % n_pins].array, 0.8, 1024, SCAN_MFMA, True, 0.95, 5))
+        if ahead and k + ahead < n:
+            pipe.prefetch(pins[(k + ahead) % n_pins].array)
     while tickets:
         t = tickets.popleft()
         pipe.wait(t)
