@@ -199,6 +199,12 @@ struct focr_ctx {
     uint8_t *d_needles16 = nullptr;             // class-ordered, n_h rows of 16 bytes each (verify operand)
     uint32_t *d_needle16_row = nullptr;         // class-ordered first row index into d_needles16
     void *d_vmeta = nullptr;                    // VerifyMeta by GLOBAL template index (mfma_common.h): what the verify needs about a template, 32 B
+    // the verify operand once more, ordered by GLOBAL template index, for banks that do not fit the LDS whole: a chunk of
+    // consecutive templates is then one contiguous piece (verify_chunks_kernel, rows.hip)
+    uint32_t *d_vrows_t = nullptr;              // rows of vrow_bytes each (12 when every template is at most 12 px wide, else 16), by global index
+    void *d_vmeta_t = nullptr;                  // VerifyMeta by global index whose row0 counts rows of d_vrows_t
+    std::vector<uint32_t> h_vrow0_t;            // [n_templates + 1] first row of every template in d_vrows_t
+    uint32_t vrow_bytes = 0;                    // 0: no such copy (a template wider than 16 px)
     uint32_t *d_t_w = nullptr, *d_t_h = nullptr, *d_t_letter = nullptr;  // by global template index
 
     // pages: [n_pages][rows_alloc][pitch] ink-high u8, zero padded
@@ -258,6 +264,7 @@ struct focr_ctx {
     uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
     uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
     uint32_t row_seg_shift = 0; // log2 of the x-segment width of the buckets (0: not chosen yet for this setup; rows.hip, row_segments)
+    bool chunked_verify = true; // hits-first tail, banks above the LDS: verify in chunk passes (false: template rows gathered from global memory; FOCR_VERIFY_GLOBAL, A/B)
     int tail_mode = 1;          // focr_ctx_set_row_tail(): 0 = the legacy tail (radix sort + verify + compaction), 1 = hits-first row tail
                                 // (verify in flush order, hits bucketed + sorted: the default), 2 = round 3's row tail (sort, verify, compact)
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;

@@ -92,6 +92,10 @@ static void free_bank(focr_ctx *c) {
     free_dev(c->d_needles16);
     free_dev(c->d_needle16_row);
     free_dev(c->d_vmeta);
+    free_dev(c->d_vrows_t);
+    free_dev(c->d_vmeta_t);
+    c->h_vrow0_t.clear();
+    c->vrow_bytes = 0;
     free_dev(c->d_t_w);
     free_dev(c->d_t_h);
     free_dev(c->d_t_letter);
@@ -235,6 +239,7 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         int cus = 0;
         FOCR_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         c->n_cus = (unsigned)std::max(cus, 1);
+        c->chunked_verify = getenv("FOCR_VERIFY_GLOBAL") == nullptr;
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
         FOCR_HIP(c, hipMalloc(&c->d_counter, COUNTER_BYTES));

@@ -150,10 +150,7 @@ __host__ __device__ inline int prefilter_cin(float S, float v) {
 // MFMAs take 0.3 ms).  A wave whose range is exhausted goes on with the next XCD's; it stops once it has seen every range
 // exhausted, which every wave reaches after at most n_xc extra requests.
 // The queue (QUEUE_XCDS counters, QUEUE_STRIDE dwords apart) is zeroed by the clear launch that opens every scan (launch_scan_mfma, ClearList).
-#ifndef FOCR_ITEMS_PER_TICKET
-#define FOCR_ITEMS_PER_TICKET 4
-#endif
-constexpr uint32_t ITEMS_PER_TICKET = FOCR_ITEMS_PER_TICKET;
+constexpr uint32_t ITEMS_PER_TICKET = 4;  // 2 / 4 / 8 measured: 0.73 / 0.70 / 0.70 ms for a 6-N-tile bank
 struct ItemTaker {
     uint32_t *queue;
     uint32_t n_items, n_xc, per_xc, cur_q, hops, ticket_v;

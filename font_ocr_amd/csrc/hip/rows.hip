@@ -415,6 +415,125 @@ __global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_list
     }
 }
 
+// Banks whose verify operand does not fit the LDS whole (BASELINE configs[2]: 1 520 templates, 287 KB of 12-byte rows + 48 KB
+// of records): the operand is cut into CHUNKS of consecutive templates (by global template index; d_vrows_t / d_vmeta_t are
+// ordered that way) that do fit, and the kernel makes one pass over its candidates per chunk — chunk rows and records staged in
+// LDS, every wave walking its own piece of the list, collecting the keys whose template lies in the chunk in a wave-private
+// queue in LDS and verifying them 64 at a time, so every verify step runs on full waves whatever the mix of templates in the
+// list.  Reading the keys once more per chunk costs 8 B per candidate and pass, so chunks are as large as the LDS allows (one
+// workgroup per CU: BASELINE configs[2] in 3 chunks 2.19 ms alone on the chip; 5 chunks of 80 KB 3.14 ms; the template rows
+// gathered from global memory, verify_list_kernel<0>, 3.35 ms — a 64-way gather per wave instruction).
+constexpr uint32_t MAX_VERIFY_CHUNKS = 16, CHUNK_QUEUE = 128;
+struct ChunkTable {
+    uint32_t n;
+    uint32_t t_lo[MAX_VERIFY_CHUNKS + 1];    // chunk k: templates [t_lo[k], t_lo[k + 1])
+    uint32_t row_lo[MAX_VERIFY_CHUNKS + 1];  // ... rows [row_lo[k], row_lo[k + 1]) of d_vrows_t
+    uint32_t max_templates, max_rows;        // of any chunk (LDS layout)
+};
+template <int ROWB>
+__global__ __launch_bounds__(VERIFY_THREADS, 4) void verify_chunks_kernel(
+    const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, const ChunkTable ct,
+    const uint32_t *__restrict__ vrows_t, const VerifyMeta *__restrict__ vmeta_t, const RowHist rows, float *__restrict__ sims, uint32_t *__restrict__ slots,
+    uint32_t *__restrict__ row_hits) {
+    // LDS: [chunk records: max_templates x 32 B][chunk rows: max_rows x ROWB][per wave: CHUNK_QUEUE keys, CHUNK_QUEUE list positions]
+    extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    constexpr uint32_t ROWDW = ROWB / 4;
+    VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
+    uint32_t *rows_lds = reinterpret_cast<uint32_t *>(verify_lds + 2 * ct.max_templates);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t *q_key = reinterpret_cast<uint64_t *>(rows_lds + (size_t)((ct.max_rows * ROWDW + 3) & ~3u)) + (size_t)wv * CHUNK_QUEUE;
+    uint32_t *q_pos = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(rows_lds + (size_t)((ct.max_rows * ROWDW + 3) & ~3u)) + (size_t)(VERIFY_THREADS / 64) * CHUNK_QUEUE) +
+                      (size_t)wv * CHUNK_QUEUE;
+    const unsigned long long n = min(*n_cand_p, cap);
+    // the wave's own piece of the list: whole groups of 64
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * (VERIFY_THREADS / 64);
+    const unsigned long long per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
+    const unsigned long long wb = min(n, ((unsigned long long)blockIdx.x * (VERIFY_THREADS / 64) + wv) * per_wave), we = min(n, wb + per_wave);
+    // one verify step over the first `m` queued candidates (m <= 64): the reference arithmetic, the hit's slot in its bucket
+    auto step = [&](uint32_t m, const VerifyMeta *meta_c, const uint32_t *rows_c) {
+        const bool valid = (uint32_t)lane < m;
+        const uint64_t key = valid ? q_key[lane] : 0;
+        const uint32_t pos = valid ? q_pos[lane] : 0;
+        float sim = 0.f;
+        bool emit = false;
+        if (valid) {
+            if (ROWB == 12) emit = verify_candidate_narrow(key, va, rows_c, meta_c, &sim);
+            else emit = verify_candidate_meta<true>(key, va, reinterpret_cast<const v4i *>(rows_c), meta_c, &sim);
+        }
+        const uint32_t r = emit ? row_of_key(key, rows) : 0xffffffffu;
+        uint32_t slot = 0xffffffffu;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(emit);
+        while (todo) {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
+            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
+            uint32_t start = 0;
+            if (lane == (int)__builtin_ctzll(peers)) start = atomicAdd(row_hits + r0, (uint32_t)__builtin_popcountll(peers));
+            start = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)__builtin_ctzll(peers));
+            if (r == r0) slot = start + __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            todo &= ~peers;
+        }
+        if (valid) {
+            sims[pos] = sim;
+            slots[pos] = slot;
+        }
+    };
+    for (uint32_t k = 0; k < ct.n; k++) {
+        const uint32_t t_lo = ct.t_lo[k], t_hi = ct.t_lo[k + 1], row_lo = ct.row_lo[k], n_rows_c = ct.row_lo[k + 1] - row_lo;
+        __syncthreads();  // the previous chunk's readers are done
+        for (uint32_t i = threadIdx.x; i < 2 * (t_hi - t_lo); i += VERIFY_THREADS) verify_lds[i] = reinterpret_cast<const v4i *>(vmeta_t + t_lo)[i];
+        for (uint32_t i = threadIdx.x; i < n_rows_c * ROWDW; i += VERIFY_THREADS) rows_lds[i] = vrows_t[(size_t)row_lo * ROWDW + i];
+        __syncthreads();
+        // records by global template index and rows by their index in d_vrows_t, as the verify functions address them
+        const VerifyMeta *meta_c = meta - t_lo;
+        const uint32_t *rows_c = rows_lds - (size_t)row_lo * ROWDW;
+        uint32_t count = 0;  // wave-uniform: queued candidates of this chunk
+        for (unsigned long long i0 = wb; i0 < we; i0 += 4 * 64) {
+            // four groups of keys per round, their loads in flight together (the walk is latency-bound otherwise: one round trip per group and pass)
+            uint64_t key4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long i = i0 + 64 * q + lane;
+                key4[q] = i < we ? cand[i] : ~0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long i = i0 + 64 * q + lane;
+                const bool valid = i < we;
+                const uint64_t key = key4[q];
+                const uint32_t t = va.fmt.t(key);
+                // a template index outside the bank belongs to no chunk: such a key (cannot happen) is given to the last chunk, whose
+                // verify flags it instead of leaving its outputs unwritten
+                const bool in = valid && ((t >= t_lo && t < t_hi) || (k + 1 == ct.n && t >= t_hi));
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(in);
+                if (mask) {
+                    if (in) {
+                        const uint32_t p = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        q_key[p] = key;
+                        q_pos[p] = (uint32_t)i;
+                    }
+                    count += (uint32_t)__builtin_popcountll(mask);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (count >= 64) {
+                        step(64, meta_c, rows_c);
+                        const uint32_t rest = count - 64;  // < 64: moves to the front of the queue
+                        const uint64_t kk = (uint32_t)lane < rest ? q_key[64 + lane] : 0;
+                        const uint32_t pp = (uint32_t)lane < rest ? q_pos[64 + lane] : 0;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if ((uint32_t)lane < rest) {
+                            q_key[lane] = kk;
+                            q_pos[lane] = pp;
+                        }
+                        count = rest;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                }
+            }
+        }
+        if (count) step(count, meta_c, rows_c);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // hit -> its dense place: hbase[bucket] + slot (no atomics: the slots were handed out by the verify)
 __global__ __launch_bounds__(256) void hit_scatter_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap,
                                                           const RowHist rows, const uint32_t *__restrict__ hbase, const float *__restrict__ sims,
@@ -635,6 +754,51 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
         size_t lds;
         uint32_t all_rows;
         const int mode = verify_mode(c, &lds, &all_rows);
+        if (mode == 0 && c->vrow_bytes && c->chunked_verify) {
+            // the operand does not fit the LDS whole: chunks of consecutive templates that do (verify_chunks_kernel)
+            const bool narrow = c->vrow_bytes == 12;
+            const size_t queue_bytes = (size_t)(VERIFY_THREADS / 64) * CHUNK_QUEUE * 12 + 64;
+            const size_t budget = ((size_t)150 << 10) - queue_bytes;  // one workgroup per CU: fewer, larger chunks beat more waves per CU (above)
+            ChunkTable ct{};
+            size_t bytes = 0;
+            uint32_t t0 = 0;
+            bool ok = true;
+            for (uint32_t t = 0; t <= c->n_templates && ok; t++) {
+                const size_t add = t < c->n_templates ? sizeof(VerifyMeta) + (size_t)(c->h_vrow0_t[t + 1] - c->h_vrow0_t[t]) * c->vrow_bytes : 0;
+                if (t == c->n_templates || bytes + add > budget) {
+                    if (t == t0 || ct.n == MAX_VERIFY_CHUNKS) {
+                        ok = false;  // a single template above the budget, or too many chunks: global loads after all
+                        break;
+                    }
+                    ct.t_lo[ct.n] = t0;
+                    ct.row_lo[ct.n] = c->h_vrow0_t[t0];
+                    ct.max_templates = std::max(ct.max_templates, t - t0);
+                    ct.max_rows = std::max(ct.max_rows, c->h_vrow0_t[t] - c->h_vrow0_t[t0]);
+                    ct.n++;
+                    t0 = t;
+                    bytes = 0;
+                }
+                bytes += add;
+            }
+            if (ok) {
+                ct.t_lo[ct.n] = (uint32_t)c->n_templates;
+                ct.row_lo[ct.n] = c->h_vrow0_t[c->n_templates];
+                const size_t lds_c = (size_t)ct.max_templates * sizeof(VerifyMeta) + (((size_t)ct.max_rows * (c->vrow_bytes / 4) + 3) & ~(size_t)3) * 4 + queue_bytes;
+                const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
+#define FOCR_VERIFY_CHUNKS(R)                                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_chunks_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);                 \
+    hipLaunchKernelGGL(verify_chunks_kernel<R>, dim3(nbc), dim3(VERIFY_THREADS), lds_c, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
+                       ct, (const uint32_t *)c->d_vrows_t, (const VerifyMeta *)c->d_vmeta_t, c->row_hist, csims, cslots, hits)
+                if (narrow) {
+                    FOCR_VERIFY_CHUNKS(12);
+                } else {
+                    FOCR_VERIFY_CHUNKS(16);
+                }
+#undef FOCR_VERIFY_CHUNKS
+                FOCR_HIP(c, hipGetLastError());
+                goto verified;
+            }
+        }
         const unsigned per_cu = mode == 2 ? 2u : (mode == 0 && c->n_templates * sizeof(VerifyMeta) <= ((size_t)64 << 10) ? 2u : 1u);
         const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus * per_cu));
 #define FOCR_VERIFY_LIST(M)                                                                                                                                      \
@@ -651,6 +815,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
 #undef FOCR_VERIFY_LIST
         FOCR_HIP(c, hipGetLastError());
     }
+verified:
     FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
     hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6, c->d_res + 5);
     FOCR_HIP(c, hipGetLastError());

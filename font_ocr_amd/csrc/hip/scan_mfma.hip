@@ -93,10 +93,7 @@ int launch_clear(focr_ctx *c, const ClearList &l) {
 //         the tile) down, which gives the kept box's sums and W.
 //   PAIR: the kept box is itself a size class of the pass (BASELINE configs[1]: 8x15 beside 9x15): its plane comes out of
 //         the same launch (its statistics are the kept box's), one launch instead of two.
-#ifndef FOCR_STATS_STY
-#define FOCR_STATS_STY 32  // window rows per block (experiment builds: 64 = less halo, fewer blocks per CU)
-#endif
-constexpr int STX = 64, STY = FOCR_STATS_STY, SLDW = 21;
+constexpr int STX = 64, STY = 32, SLDW = 21;  // 32 window rows per block (64 = less halo, fewer blocks per CU: measured, no gain)
 static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h - 1) * (SLDW * 4 + STX * 4 + STX * 2); }
 
 struct StatsOut {  // what a statistics launch writes for one size class
@@ -531,6 +528,30 @@ int build_mfma_bank(focr_ctx *c, const uint8_t *dense) {
         }
         FOCR_HIP(c, hipMalloc(&c->d_vmeta, vm.size() * sizeof(VerifyMeta)));
         FOCR_HIP(c, hipMemcpy(c->d_vmeta, vm.data(), vm.size() * sizeof(VerifyMeta), hipMemcpyHostToDevice));
+    }
+    {  // the same operand by GLOBAL template index, as rows of 12 bytes (every template at most 12 px wide) or 16: chunks of consecutive
+       // templates are contiguous there (verify_chunks_kernel, rows.hip: banks whose operand does not fit the LDS whole)
+        uint32_t max_w = 0;
+        for (const TemplateConst &tc : c->h_tconst) max_w = std::max<uint32_t>(max_w, tc.n_w);
+        c->vrow_bytes = max_w <= 12 ? 12u : max_w <= 16 ? 16u : 0u;
+        c->h_vrow0_t.assign(c->n_templates + 1, 0);
+        if (c->vrow_bytes) {
+            std::vector<size_t> ci_of(c->n_templates, 0);
+            for (size_t ci = 0; ci < c->h_tconst.size(); ci++) ci_of[c->h_tconst[ci].index] = ci;
+            for (size_t t = 0; t < c->n_templates; t++) c->h_vrow0_t[t + 1] = c->h_vrow0_t[t] + c->h_tconst[ci_of[t]].n_h;
+            std::vector<uint8_t> rows((size_t)c->h_vrow0_t[c->n_templates] * c->vrow_bytes + 16, 0);
+            std::vector<VerifyMeta> vm(c->n_templates);
+            for (size_t t = 0; t < c->n_templates; t++) {
+                const TemplateConst &tc = c->h_tconst[ci_of[t]];
+                const uint8_t *nd = dense + c->h_needle_off[ci_of[t]];
+                for (uint32_t j = 0; j < tc.n_h; j++) memcpy(&rows[((size_t)c->h_vrow0_t[t] + j) * c->vrow_bytes], nd + (size_t)j * tc.n_w, tc.n_w);
+                vm[t] = VerifyMeta{tc.s_n, tc.n_recip, tc.rnorm_n, (uint16_t)tc.n_w, (uint16_t)tc.n_h, c->h_vrow0_t[t]};
+            }
+            FOCR_HIP(c, hipMalloc((void **)&c->d_vrows_t, rows.size()));
+            FOCR_HIP(c, hipMemcpy(c->d_vrows_t, rows.data(), rows.size(), hipMemcpyHostToDevice));
+            FOCR_HIP(c, hipMalloc(&c->d_vmeta_t, vm.size() * sizeof(VerifyMeta)));
+            FOCR_HIP(c, hipMemcpy(c->d_vmeta_t, vm.data(), vm.size() * sizeof(VerifyMeta), hipMemcpyHostToDevice));
+        }
     }
     FOCR_HIP(c, hipMalloc((void **)&c->d_needle16_row, n16_row.size() * 4));
     FOCR_HIP(c, hipMemcpy(c->d_needle16_row, n16_row.data(), n16_row.size() * 4, hipMemcpyHostToDevice));

@@ -192,41 +192,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 // window: one f16 threshold-plane value per size class and M-tile (mfma_common.h) stays in a register for the whole item
 // and the int32 C-in -(floor(S * v) - 2) is formed from it once per item — no per-class int32 table, no reload of C-in rows
 // in the middle of the N-tile loop when the size class changes.
-#ifndef FOCR_V2S_NW
-#define FOCR_V2S_NW 16  // waves per workgroup (one workgroup per CU); experiment builds: make hip EXTRA=-DFOCR_V2S_NW=12
-#endif
-#ifndef FOCR_V2S_OCC
-#define FOCR_V2S_OCC 4  // waves per SIMD the register budget allows (128 VGPRs); experiment builds: 5 = 96 VGPRs, a fifth wave slot per SIMD left to other kernels
-#endif
-#ifdef FOCR_V2S_VARIANTS
-// experiment builds only: timing of the kernel with parts of the candidate path cut out (results are wrong then)
-__device__ int focr_v2s_variant;
-extern "C" int focr_debug_v2s_variant(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(focr_v2s_variant), &v, sizeof v) == hipSuccess ? 0 : 1; }
-// ... and how often the candidate path runs: [0] items, [1] visits (N-tiles with a candidate), [2] M-tiles looked into, [3] registers with a candidate
-__device__ unsigned long long focr_v2s_counts[4];
-extern "C" int focr_debug_v2s_counts(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(focr_v2s_counts), 32) != hipSuccess) return 1;
-    const unsigned long long z[4] = {0, 0, 0, 0};
-    return reset && hipMemcpyToSymbol(HIP_SYMBOL(focr_v2s_counts), z, 32) != hipSuccess ? 1 : 0;
-}
-#define V2S_COUNT(i) v2s_cnt[i]++;
-#else
-#define V2S_COUNT(i)
-#endif
-#ifdef FOCR_V2S_PROF
-// experiment builds only (make hip EXTRA=-DFOCR_V2S_PROF; tools/prof2s.py): per-phase wave time (s_memtime ticks), summed over all waves
-__device__ unsigned long long focr_prof2[8];
-#define PROF2(i)                                                      \
-    {                                                                 \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        prof_acc[i] += now_ - prof_t;                                 \
-        prof_t = now_;                                                \
-    }
-#else
-#define PROF2(i)
-#endif
+// 16 waves per workgroup, one workgroup per CU, 128 VGPRs (4 waves per SIMD).  Measured and not adopted (dead ends): 12- and
+// 8-wave workgroups, 96 VGPRs (a fifth wave slot per SIMD left to other kernels).
+constexpr int V2S_NW = 16, V2S_OCC = 4;
 template <int KSTEPS, int RPG, int MT, int NW, int NV>
-__global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
+__global__ __launch_bounds__(NW * 64, V2S_OCC) void scan_mfma2s_kernel(
     const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, const uint64_t *__restrict__ live_list,
     const uint32_t *__restrict__ live_count, uint32_t page_base, const v4i *__restrict__ qbank, uint32_t n_tiles16, const MfmaSegs segs, uint32_t Lpitch, uint32_t Lrows,
     const PlaneArgs P, const uint32_t *__restrict__ tglobal, const KeyFmt fmt, uint64_t *__restrict__ cand,
@@ -270,31 +240,14 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
     ItemTaker take;
     take.init(queue, n_items, lane);
     v4i afrag[MT][KSTEPS];
-#ifdef FOCR_V2S_VARIANTS
-    const int variant = __builtin_amdgcn_readfirstlane(focr_v2s_variant);
-    uint32_t v2s_cnt[4] = {0, 0, 0, 0};
-#endif
-#ifdef FOCR_V2S_PROF
-    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
-#endif
     for (uint32_t item; take.next(item);) {
-        PROF2(5)  // waiting for the ticket
-        V2S_COUNT(0)
-#ifdef FOCR_V2S_PROF
-        prof_acc[7]++;
-#endif
         const uint32_t m0 = item * MT;
         uint32_t px[MT], py[MT], pp[MT];
         bool pv[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             pv[mt] = m0 + mt < total_mt;
-#ifdef FOCR_V2S_VARIANTS
-            const uint64_t e = (variant & 16) ? (uint64_t)((m0 + mt) % 40) | ((uint64_t)(((m0 + mt) / 40) % 590) << 12) | ((uint64_t)(((m0 + mt) / 23600) & 127) << 32)
-                                              : live_list[pv[mt] ? m0 + mt : total_mt - 1];
-#else
             const uint64_t e = live_list[pv[mt] ? m0 + mt : total_mt - 1];
-#endif
             px[mt] = 16 * (uint32_t)(e & 0xfff);
             py[mt] = 1 + (uint32_t)((e >> 12) & 0xfffff);  // y = 0 is never searched (src/ncc.cpp:302)
             pp[mt] = (uint32_t)(e >> 32);
@@ -310,17 +263,6 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
             asm volatile("" : "+v"(po[v]));
         }
         float nrm[MT][NV];  // threshold-plane values of the lane's own window px + r, one per size class
-#ifdef FOCR_V2S_VARIANTS
-        if (variant & 8) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) nrm[mt][v] = 900.f + (float)lane;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ks++) afrag[mt][ks] = v4i{(int)px[mt] * 77 + lane, (int)py[mt] * 1315423911 + lane * 31, (int)pp[mt] + lane * 7, lane * 0x01010101};
-            }
-        } else {
-#endif
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const uint8_t *np = reinterpret_cast<const uint8_t *>(P.planes + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt]);  // wave-uniform
@@ -352,15 +294,7 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
                 afrag[mt][ks] = a;
             }
         }
-#ifdef FOCR_V2S_VARIANTS
-        }
-#endif
         take.request();  // the next item's ticket
-        PROF2(0)
-#ifdef FOCR_V2S_PROF
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // the item's loads (the ticket may stay outstanding)
-        PROF2(1)
-#endif
         // C-in of the lane's own window per size class (prefilter_cin, mfma_common.h; a window the class never emits at holds
         // +inf, which comes out as an unreachable threshold).  M-tiles past the end of the enumeration repeat the last live one:
         // they are dropped where candidates are emitted (rare path), not here
@@ -407,20 +341,12 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
                     m = max(max(m, acc[mt][0]), acc[mt][1]);
                     m = max(max(m, acc[mt][2]), acc[mt][3]);
                 }
-#ifdef FOCR_V2S_VARIANTS
-                if (variant & 1) continue;
-#endif
                 if (__builtin_amdgcn_ballot_w64(m > 0) != 0) {  // wave-uniform; taken for roughly one N-tile in ten
-                    PROF2(2)
-#ifdef FOCR_V2S_VARIANTS
-                    if (variant & 2) { asm volatile("s_nop 0"); continue; }
-#endif
                     // The candidate path is kept short (a sixth of the kernel at BASELINE configs[1], where six windows in ten that pass
                     // are real matches): ONE LDS read per visit for the lane's four template ids (lane (r, g), register i: template
                     // 4g + i of the tile, window px + r), one compare per register — its mask is the ballot — and a key whose high
                     // word and low-word base are formed once per M-tile (x = px + r and the template id fill disjoint bit fields of
                     // the low word: launch_v2s checks bt + bx <= 32), so a staged key costs one v_or3 and one LDS write.
-                    V2S_COUNT(1)
                     v4i tg4 = reinterpret_cast<const v4i *>(tg_lds)[nt * 4 + g];
                     if (nt >= dead_from) {  // the class's last tiles: dead / padding slots (id ~0) never emit.  Wave-uniform, rare
 #pragma unroll
@@ -433,10 +359,6 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
                         if (!pv[mt]) continue;  // past the end of the enumeration (a repeat of the last live M-tile): wave-uniform
                         const int mmt = max(max(acc[mt][0], acc[mt][1]), max(acc[mt][2], acc[mt][3]));
                         if (__builtin_amdgcn_ballot_w64(mmt > 0) == 0) continue;  // wave-uniform
-#ifdef FOCR_V2S_VARIANTS
-                        if (variant & 4) { asm volatile("s_nop 0"); continue; }
-#endif
-                        V2S_COUNT(2)
                         uint32_t pg = pp[mt], yy = py[mt], xx = px[mt];
                         asm volatile("" : "+s"(pg), "+s"(yy), "+s"(xx));  // keep the key arithmetic inside this rare block
                         const uint64_t kb = fmt.pack(page_base + pg, yy, xx, 0);  // scalar
@@ -446,45 +368,26 @@ __global__ __launch_bounds__(NW * 64, FOCR_V2S_OCC) void scan_mfma2s_kernel(
                             const bool ok = acc[mt][i] > 0;
                             const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
                             if (!okmask) continue;  // wave-uniform
-                            V2S_COUNT(3)
                             const uint32_t cnt = (uint32_t)__builtin_popcountll(okmask);
                             if (wcount + cnt > WBUF) {
-                                PROF2(3)
                                 flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
                                 wcount = 0;
-                                PROF2(4)
-#ifdef FOCR_V2S_PROF
-                                prof_acc[6] += 1ull << 32;  // flushes in the high half, visits in the low half
-#endif
                             }
                             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(okmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okmask, 0u));
                             if (ok) reinterpret_cast<uint2 *>(wbuf)[wcount + pos] = uint2{k_lo | (uint32_t)tg4[i], k_hi};
                             wcount += cnt;
                         }
                     }
-                    PROF2(3)
-#ifdef FOCR_V2S_PROF
-                    prof_acc[6]++;
-#endif
                 }
             }
         }
-        PROF2(2)
     }
     if (wcount) flush_wave_candidates(wbuf, wcount, lane, cand, cand_counter, cand_cap, rows);
-#ifdef FOCR_V2S_VARIANTS
-    if (lane == 0)
-        for (int i = 0; i < 4; i++) atomicAdd(&focr_v2s_counts[i], (unsigned long long)v2s_cnt[i]);
-#endif
-#ifdef FOCR_V2S_PROF
-    if (lane == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&focr_prof2[i], prof_acc[i]);
-#endif
 }
 
 template <int KSTEPS, int RPG, int NV>
 static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, unsigned n_cus) {
-    constexpr int MT = 4, NW = FOCR_V2S_NW;
+    constexpr int MT = 4, NW = V2S_NW;
     const uint32_t n_tiles16 = L.n_tiles16;
     const size_t lds = (size_t)n_tiles16 * KSTEPS * 1024 + (size_t)NW * WBUF * 8 + (size_t)n_tiles16 * 16 * 4;
     const uint64_t total_mt = (uint64_t)L.mtx * L.n_rows * c->sub_np;
@@ -504,16 +407,6 @@ static void launch_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, un
     c->launch_end();
 }
 
-#ifdef FOCR_V2S_PROF
-extern "C" int focr_debug_prof2(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(focr_prof2), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(focr_prof2), z, sizeof z);
-    }
-    return 0;
-}
-#endif
 
 int dispatch_mfma_v2s(focr_ctx *c, const MfmaLaunch &L, const PlaneArgs &A3, unsigned n_cus) {
     // the kernel forms a key's low word from disjoint bit fields (x and template id); banks hold <= 65535 templates, pages <= 65535 px
@@ -560,25 +453,12 @@ static void launch_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
 int dispatch_mfma_v2(focr_ctx *c, const MfmaLaunch &L, unsigned n_cus) {
     const uint32_t ks = L.ksteps, rpg = L.layout;
     // 16 waves x 4 M-tiles per CU measured best for <= 4 K-steps (8 x 8 and 12 x 6 were 6-9 % slower at C2); the
-    // 5..8 K-step layouts need the registers of 8 waves per CU.  -DFOCR_MFMA_EXPERIMENTS compiles the alternatives
-    // back in (selected with FOCR_MFMA_CFG = 0: 8 x 8, 1: 12 x 6).
-#ifdef FOCR_MFMA_EXPERIMENTS
-    int cfg = 3;
-    if (const char *e = getenv("FOCR_MFMA_CFG")) cfg = atoi(e);
-#define CASE(K, R, M)                                                  \
-    case (K) * 10 + (R):                                               \
-        if (cfg == 1 && (K) <= 4) launch_v2<K, R, 6, 12>(c, L, n_cus);      \
-        else if (cfg == 0 && (K) <= 4) launch_v2<K, R, 8, 8>(c, L, n_cus);  \
-        else if ((K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus);        \
-        else launch_v2<K, R, M, 8>(c, L, n_cus);                       \
-        break;
-#else
+    // 5..8 K-step layouts need the registers of 8 waves per CU.
 #define CASE(K, R, M)                                           \
     case (K) * 10 + (R):                                        \
         if ((K) <= 4) launch_v2<K, R, 4, 16>(c, L, n_cus);      \
         else launch_v2<K, R, M, 8>(c, L, n_cus);                \
         break;
-#endif
     switch (ks * 10 + rpg) {
         CASE(1, 1, 8) CASE(2, 1, 8) CASE(3, 1, 8) CASE(4, 1, 8) CASE(5, 1, 4) CASE(6, 1, 4) CASE(7, 1, 4) CASE(8, 1, 4)
         CASE(1, 2, 8) CASE(2, 2, 8) CASE(3, 2, 8) CASE(4, 2, 8)

@@ -409,6 +409,33 @@ def test_random_banks_all_layouts(scanner, mode, shapes):
         _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), _oracle_lists(pages, bank, thr, 1024), f"{shapes} thr={thr}")
 
 
+@pytest.mark.parametrize("shapes,per_shape", [([(16, 24), (14, 20)], 220), ([(9, 16), (8, 15), (12, 12)], 700)], ids=["rows16", "rows12"])
+def test_banks_above_the_lds_verify_in_chunks(scanner, shapes, per_shape):
+    """Round 4: a bank whose verify operand does not fit the LDS whole (here 180 KB of 16-byte rows / 330 KB of 12-byte rows) is
+    verified in chunk passes (verify_chunks_kernel, rows.hip: chunk rows in LDS, a wave-private queue per chunk); same lists as
+    the reference kernel, also through round 3's row tail (template rows gathered from global memory)."""
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(str(shapes).encode()))
+    bank = _random_bank(rng, shapes, per_shape)
+    pages = rng.integers(0, 256, (2, 57, 131), dtype=np.uint8)
+    pages[rng.random(pages.shape) < 0.5] = 255
+    for k, t in enumerate(range(0, len(bank), 9)):  # plant templates all over the bank: every chunk gets hits
+        nd = bank.needle(t)
+        y, x = 1 + (5 * k) % (57 - nd.shape[0]), 1 + (13 * k) % (131 - nd.shape[1])
+        pages[k % 2, y:y + nd.shape[0], x:x + nd.shape[1]] = 255 - nd
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    want = _oracle_lists(pages, bank, 0.6, 1024)
+    for tail in (1, 2, 1):
+        scanner.set_row_tail(tail)
+        scanner.scan(0.6, 1024, MFMA1)
+        offsets, m = scanner.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want, f"{shapes} tail={tail}")
+    names = [li["name"] for li in scanner.launches()]
+    assert names, names
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_c3_bank_16_shifts(scanner, bank_x2y2, mode):
     """configs[2] bank: 95 glyphs x 16 sub-pixel shifts = 1520 templates in four size classes."""

@@ -23,7 +23,6 @@ python3 bench.py --no-cpu-baseline --with-upload --steps 60 > $out/bench_c2_uplo
 python3 bench.py --no-cpu-baseline --no-e2e --force-gather --steps 60 > $out/bench_c2_force_gather.json 2> $out/bench_c2_force_gather.err; say "force-gather done"
 python3 bench.py --no-cpu-baseline --no-e2e --in-flight 4 --steps 60 > $out/bench_c2_inflight4.json 2> /dev/null; say "in-flight 4 done"
 bash tools/timeline.sh > $out/timeline_bench_c2.log 2>&1; say "timeline done"
-FOCR_HIP_LIB=$repo/tools/bin/libfocr_hip_var.so python3 tools/variants.py > $out/scan_variants.log 2>&1; say "variants done"
 tools/bin/mfma_shape > $out/mfma_shape.log 2>&1; say "mfma_shape done"
 pmc fetch "FETCH_SIZE" python3 $repo/tools/kbench.py
 pmc write "WRITE_SIZE" python3 $repo/tools/kbench.py
