@@ -115,6 +115,7 @@ __host__ __device__ inline uint32_t row_of_key(uint64_t key, const RowHist &h) {
 // Item queues of the persistent scan kernels (scan_mfma2.hip): one per launch, QUEUE_XCDS counters QUEUE_STRIDE dwords
 // apart, all zeroed with the counters by the clear launch at the start of a scan (ClearList).
 constexpr uint32_t COUNTER_WORDS = 64, QUEUE_XCDS = 8, QUEUE_STRIDE = 32, MAX_SCAN_QUEUES = 128;
+constexpr uint32_t TAIL_DONE_WORD = 56, ORDER_DONE_WORD = 57;  // d_counter words: workgroups of the verify / of unit_prefix that have finished ("last workgroup" work)
 constexpr size_t COUNTER_BYTES = (COUNTER_WORDS + (size_t)MAX_SCAN_QUEUES * QUEUE_XCDS * QUEUE_STRIDE) * sizeof(uint32_t);
 
 namespace focr {

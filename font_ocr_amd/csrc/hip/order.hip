@@ -310,29 +310,10 @@ __global__ __launch_bounds__(256) void unit_hist_kernel(const uint64_t *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void unit_prefix_kernel(uint32_t T, uint32_t n_pages, const uint32_t *__restrict__ page_unit0, uint32_t *__restrict__ uhist,
-                                                          uint32_t cap, uint32_t *__restrict__ seg_count, uint32_t n_seg_padded) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // (page, t) call
-    if (s >= n_seg_padded) return;
-    if (s >= n_pages * T) {  // the padding the prefix kernel reads 16 bytes at a time
-        seg_count[s] = 0;
-        return;
-    }
-    const uint32_t p = s / T, t = s % T;
-    uint32_t run = 0;
-    for (uint32_t u = page_unit0[p]; u < page_unit0[p + 1]; u++) {
-        const uint32_t v = uhist[(size_t)u * T + t];
-        uhist[(size_t)u * T + t] = run;
-        run += v;
-    }
-    seg_count[s] = min(run, cap);  // the reference stops the call at n_out matches (src/ncc.cpp:225-227)
-}
-
-// exclusive prefix of n u32 counts -> n + 1 u64 offsets, one workgroup, coalesced 16-byte loads (cnt padded with zeros to a
-// multiple of 4 entries behind n)
+// exclusive prefix of n u32 counts -> n + 1 u64 offsets by ONE 1 024-thread workgroup, coalesced 16-byte loads (cnt padded with zeros to a
+// multiple of 4 entries behind n): a kernel of its own (the sorting form) or the last workgroup of unit_prefix_kernel
 typedef unsigned int ov4u __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(1024) void offsets_u64_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off) {
-    __shared__ uint64_t wave_sum[16];
+__device__ __forceinline__ void offsets_u64_block(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off, uint64_t *wave_sum) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t seg = ((n + 15) / 16 + 255) / 256 * 256, b = min(n, wv * seg), e = min(n, b + seg);
     const ov4u *cnt4 = reinterpret_cast<const ov4u *>(cnt);
@@ -372,6 +353,45 @@ __global__ __launch_bounds__(1024) void offsets_u64_kernel(const uint32_t *__res
         uint64_t tot = 0;
         for (int q = 0; q < 16; q++) tot += wave_sum[q];
         off[n] = tot;
+    }
+}
+__global__ __launch_bounds__(1024) void offsets_u64_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off) {
+    __shared__ uint64_t wave_sum[16];
+    offsets_u64_block(cnt, n, off, wave_sum);
+}
+
+// one thread per (page, t) call: running sum over the page's units -> the units' base ranks, the call's capped match count; the
+// kernel's LAST workgroup then turns the counts into the CSR offsets (offsets_u64_block: a launch less in the batch's chain)
+__global__ __launch_bounds__(1024) void unit_prefix_kernel(uint32_t T, uint32_t n_pages, const uint32_t *__restrict__ page_unit0, uint32_t *__restrict__ uhist,
+                                                           uint32_t cap, uint32_t *__restrict__ seg_count, uint32_t n_seg_padded, uint32_t *__restrict__ done,
+                                                           uint64_t *__restrict__ seg_offset) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint32_t is_last;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;  // (page, t) call
+    if (s < n_seg_padded) {
+        if (s >= n_pages * T) {  // the padding the offsets read 16 bytes at a time
+            seg_count[s] = 0;
+        } else {
+            const uint32_t p = s / T, t = s % T;
+            uint32_t run = 0;
+            for (uint32_t u = page_unit0[p]; u < page_unit0[p + 1]; u++) {
+                const uint32_t v = uhist[(size_t)u * T + t];
+                uhist[(size_t)u * T + t] = run;
+                run += v;
+            }
+            seg_count[s] = min(run, cap);  // the reference stops the call at n_out matches (src/ncc.cpp:225-227)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) *done = 0;  // for the next launch
+        offsets_u64_block(seg_count, n_pages * T, seg_offset, wave_sum);
     }
 }
 
@@ -455,10 +475,9 @@ int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t
                        (const uint32_t *)unit_begin, (const uint32_t *)unit_end, uhist);
     FOCR_HIP(c, hipGetLastError());
     const uint32_t n_seg_padded = (uint32_t)((n_seg + 3) / 4 * 4 + 4);
-    hipLaunchKernelGGL(unit_prefix_kernel, dim3((n_seg_padded + 255) / 256), dim3(256), 0, c->stream, T, n_pages, (const uint32_t *)page_unit0, uhist, c->cap,
-                       c->d_seg_count, n_seg_padded);
-    FOCR_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(offsets_u64_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->d_seg_count, (uint32_t)n_seg, c->d_seg_offset);
+    // (page, t) totals + CSR offsets: the kernel's last workgroup does the prefix (its counter is zero between launches: the last workgroup resets it)
+    hipLaunchKernelGGL(unit_prefix_kernel, dim3((n_seg_padded + 1023) / 1024), dim3(1024), 0, c->stream, T, n_pages, (const uint32_t *)page_unit0, uhist, c->cap,
+                       c->d_seg_count, n_seg_padded, c->d_counter + ORDER_DONE_WORD, c->d_seg_offset);
     FOCR_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(unit_emit_kernel, dim3(unit_blocks), dim3(256), lds, c->stream, hkeys, hsims, c->fmt, T, (uint32_t)c->sub_p0, (const uint32_t *)page_unit0,
                        n_pages, (const uint32_t *)unit_page, (const uint32_t *)unit_begin, (const uint32_t *)unit_end, (const uint32_t *)uhist, c->cap,

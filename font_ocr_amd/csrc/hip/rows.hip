@@ -36,10 +36,10 @@ int ensure_hit_capacity(focr_ctx *c, size_t want);
 // waves owns a contiguous segment (a multiple of 256 entries) and walks it 256 entries at a time — 16-byte loads, coalesced
 // — twice: sums first, then the prefix.  The arrays are padded to a multiple of 4 entries by their owner (rows_begin).
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ base,
-                                                          uint32_t *__restrict__ zero, uint64_t *__restrict__ total_out,
-                                                          uint64_t *__restrict__ max_out) {
-    __shared__ uint32_t wave_sum[16], wave_max[16];
+// the prefix as the work of ONE 1 024-thread workgroup: a kernel of its own (below), or the last workgroup of the kernel that
+// produced the counts (the hits-first tail's verify: a launch less in the batch's chain of kernels)
+__device__ __forceinline__ void row_prefix_block(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ base, uint32_t *__restrict__ zero,
+                                                 uint64_t *__restrict__ total_out, uint64_t *__restrict__ max_out, uint32_t *wave_sum, uint32_t *wave_max) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t seg = ((n + 15) / 16 + 255) / 256 * 256, b = min(n, wv * seg), e = min(n, b + seg);
     const v4u *cnt4 = reinterpret_cast<const v4u *>(cnt);
@@ -107,6 +107,37 @@ __global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__rest
         if (total_out) *total_out = tot;
         if (max_out) *max_out = m;
     }
+}
+__global__ __launch_bounds__(1024) void row_prefix_kernel(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ base,
+                                                          uint32_t *__restrict__ zero, uint64_t *__restrict__ total_out,
+                                                          uint64_t *__restrict__ max_out) {
+    __shared__ uint32_t wave_sum[16], wave_max[16];
+    row_prefix_block(cnt, n, base, zero, total_out, max_out, wave_sum, wave_max);
+}
+
+// "Am I the kernel's last workgroup?" — called by every thread of a workgroup when its work is done.  The last one to arrive sees
+// everything the others wrote (their release at the counter, its acquire here: the L1 of this CU may hold lines another CU has
+// rewritten since) and may go on with work that needs all of it: the launch it saves stood 40-50 us in a batch's chain of kernels
+// whenever other batches' kernels filled the chip.
+struct TailWork {
+    uint32_t *done;  // zeroed with the scan's counters (ClearList)
+    uint32_t n_rows;
+    uint32_t *hbase;
+    uint64_t *total_out, *max_out;
+};
+__device__ __forceinline__ bool last_workgroup(uint32_t *done) {
+    __shared__ uint32_t is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) *done = 0;  // zero between launches (and zeroed with the scan's counters anyway)
+    }
+    return is_last != 0;
 }
 
 // candidate -> its row's slots.  The candidate list is in flush order: the 64 keys of a wave come from a dozen rows, and
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
             // past the arrays' end (estimated sizes too small): nothing to sort, the batch is redone
         } else if (n > (uint32_t)CAP) {
             if (lane == 0) {
-                if (LIST) {
+                if (LIST || !big) {  // beyond the last capacity class, or no second launch was planned for this batch (estimated sizes): redo
                     atomicOr(flags_word, 2ull);
                 } else {
                     big[1 + atomicAdd(big, 1u)] = r;  // room for every row
@@ -367,9 +398,10 @@ __global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const
 template <int MODE>
 __global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_list_kernel(
     const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
-    float *__restrict__ sims, uint32_t *__restrict__ slots, uint32_t *__restrict__ row_hits) {
+    float *__restrict__ sims, uint32_t *__restrict__ slots, uint32_t *__restrict__ row_hits, const TailWork tw) {
     // LDS: [template records: n_templates x 32 B][template rows, 16 B (MODE 1) or 12 B (MODE 2) each]
     extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    __shared__ uint32_t wave_sum[16], wave_max[16];
     constexpr bool LDS = MODE == 1;
     VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
     v4i *needle_lds = verify_lds + 2 * va.n_templates;
@@ -413,6 +445,8 @@ __global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_list
             slots[i] = slot;
         }
     }
+    // the kernel's last workgroup turns the buckets' hit counts into their dense positions (+ the hit total and the largest bucket)
+    if (last_workgroup(tw.done)) row_prefix_block(row_hits, tw.n_rows, tw.hbase, nullptr, tw.total_out, tw.max_out, wave_sum, wave_max);
 }
 
 // Banks whose verify operand does not fit the LDS whole (BASELINE configs[2]: 1 520 templates, 287 KB of 12-byte rows + 48 KB
@@ -434,9 +468,10 @@ template <int ROWB>
 __global__ __launch_bounds__(VERIFY_THREADS, 4) void verify_chunks_kernel(
     const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, const ChunkTable ct,
     const uint32_t *__restrict__ vrows_t, const VerifyMeta *__restrict__ vmeta_t, const RowHist rows, float *__restrict__ sims, uint32_t *__restrict__ slots,
-    uint32_t *__restrict__ row_hits) {
+    uint32_t *__restrict__ row_hits, const TailWork tw) {
     // LDS: [chunk records: max_templates x 32 B][chunk rows: max_rows x ROWB][per wave: CHUNK_QUEUE keys, CHUNK_QUEUE list positions]
     extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
+    __shared__ uint32_t wave_sum[16], wave_max[16];
     constexpr uint32_t ROWDW = ROWB / 4;
     VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
     uint32_t *rows_lds = reinterpret_cast<uint32_t *>(verify_lds + 2 * ct.max_templates);
@@ -532,6 +567,7 @@ __global__ __launch_bounds__(VERIFY_THREADS, 4) void verify_chunks_kernel(
         if (count) step(count, meta_c, rows_c);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if (last_workgroup(tw.done)) row_prefix_block(row_hits, tw.n_rows, tw.hbase, nullptr, tw.total_out, tw.max_out, wave_sum, wave_max);
 }
 
 // hit -> its dense place: hbase[bucket] + slot (no atomics: the slots were handed out by the verify)
@@ -749,6 +785,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
     if (!csims || !cslots) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
     const unsigned cus = c->n_cus;
     uint32_t *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
+    const TailWork tw{c->d_counter + TAIL_DONE_WORD, n_rows, hbase, c->d_res + 6, c->d_res + 5};  // the verify's last workgroup does the prefix
     if (ub_c) {
         const VerifyArgs va = verify_args(c, thr_d);
         size_t lds;
@@ -788,7 +825,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
 #define FOCR_VERIFY_CHUNKS(R)                                                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_chunks_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);                 \
     hipLaunchKernelGGL(verify_chunks_kernel<R>, dim3(nbc), dim3(VERIFY_THREADS), lds_c, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
-                       ct, (const uint32_t *)c->d_vrows_t, (const VerifyMeta *)c->d_vmeta_t, c->row_hist, csims, cslots, hits)
+                       ct, (const uint32_t *)c->d_vrows_t, (const VerifyMeta *)c->d_vmeta_t, c->row_hist, csims, cslots, hits, tw)
                 if (narrow) {
                     FOCR_VERIFY_CHUNKS(12);
                 } else {
@@ -804,7 +841,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
 #define FOCR_VERIFY_LIST(M)                                                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_list_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL(verify_list_kernel<M>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
-                       M == 0 ? 0u : all_rows, c->row_hist, csims, cslots, hits)
+                       M == 0 ? 0u : all_rows, c->row_hist, csims, cslots, hits, tw)
         if (mode == 2) {
             FOCR_VERIFY_LIST(2);
         } else if (mode == 1) {
@@ -817,8 +854,10 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
     }
 verified:
     FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6, c->d_res + 5);
-    FOCR_HIP(c, hipGetLastError());
+    if (!ub_c) {  // no candidate can exist (nothing was verified): the prefix of all-zero counts, as a launch of its own
+        hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6, c->d_res + 5);
+        FOCR_HIP(c, hipGetLastError());
+    }
     return FOCR_OK;
 }
 
@@ -847,13 +886,19 @@ int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, si
     auto k1 = row_sort_kernel<1024, 4, false, true>;
     auto k2 = row_sort_kernel<4096, 1, true, true>;
     const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
-    hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins, big,
-                       flags_word, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+    hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
+                       big_expected ? big : (uint32_t *)nullptr, flags_word, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
     FOCR_HIP(c, hipGetLastError());
-    // buckets above 1 024 hits: see rows_tail (one wave unless such a bucket is expected)
-    hipLaunchKernelGGL(k2, dim3(big_expected ? cus : 1u), dim3(64), lds2, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
-                       big, flags_word, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
-    FOCR_HIP(c, hipGetLastError());
+    // Buckets above 1 024 hits (the list `big`) get a second launch only where one is expected: exact sizes know the largest bucket,
+    // estimated sizes go by the previous scan's (+ 25 %).  Without the launch a bucket that lands on the list after all is an
+    // overflow like any other estimate that proved too small (flag bit 1: the batch is redone with exact sizes) — even a launch of
+    // ONE wave that finds the list empty stood 110 us in a lane's chain of kernels (it needs 20 KB of LDS on a CU the other
+    // batches' kernels keep full: profiles/r04_timeline_bench_c2.log), for a list that BASELINE configs[1] and [2] never fill.
+    if (big_expected) {
+        hipLaunchKernelGGL(k2, dim3(cus), dim3(64), lds2, c->stream, n_rows, hbase, hits, c->d_hit_keys, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins, big, flags_word,
+                           c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
+        FOCR_HIP(c, hipGetLastError());
+    }
     return FOCR_OK;
 }
 

@@ -897,7 +897,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         size_t ub_c = c->ub_cand;
         if (use_rows && !hits_first && !nothing && (rc = rows_prefix(c))) return rc;
         if (nothing) use_rows = false;
-        bool big_expected = c->est_row_max > 1024;  // buckets above the row sort's first capacity class (rows_tail)
+        // buckets above the row sort's first capacity class get a second launch (rows.hip): estimated sizes go by the previous scan's largest + 25 %
+        bool big_expected = (uint64_t)c->est_row_max + c->est_row_max / 4 + 16 > 1024;
         if (!c->estimated) {
             unsigned long long n_cand = 0, row_max = 0;
             FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
