@@ -74,7 +74,10 @@ __host__ __device__ inline uint16_t f16_down(float x) {
     const uint32_t u = __builtin_bit_cast(uint32_t, x), sign = u >> 31, a = u & 0x7fffffffu;
     uint32_t h;
     bool inexact;
-    if (a >= 0x47800000u) {  // out of range: callers never get here
+    if (a == 0x7f800000u) {  // +-inf stays +-inf
+        h = 0x7c00;
+        inexact = false;
+    } else if (a >= 0x47800000u) {  // |x| >= 65536: the largest finite f16 towards -inf from above, -inf from below (NaN: callers never pass one)
         h = 0x7bff;
         inexact = true;
     } else if (a >= 0x38800000u) {  // normal f16
@@ -126,10 +129,28 @@ __host__ __device__ inline int32_t threshold_negL(float Lf) {
 }
 // Plane value of a window that can emit: (L - 2) / S rounded towards -inf to f16 — the "- 2" that absorbs the f32 roundings
 // of L rides in the stored value, so the scan kernel's C-in costs it one instruction less per window and size class.
-__host__ __device__ inline uint16_t plane_value(const PlaneParams &p, float Lf) {
-    Lf = __builtin_fminf(__builtin_fmaxf(Lf, -1.0e9f), 1.0e9f);
-    return f16_down((Lf - 2.0f) * p.inv_S);
+// No clamp on the way (round 4): S covers every |L| the host bounds (plane_params), and beyond that — a --threshold of +-1e30 —
+// the directed rounding does the right thing by itself: above the f16 range a positive value becomes the largest finite f16
+// (a threshold still far above any |G| < 2^24 / ... the pair never passes), a negative one -inf, which prefilter_cin turns into
+// "every pair passes"; both are lower than the true threshold, i.e. conservative.
+__host__ __device__ inline uint16_t plane_value(const PlaneParams &p, float Lf) { return f16_down((Lf - 2.0f) * p.inv_S); }
+// The same inside a kernel that has switched the f16 / f64 rounding mode of its waves to "towards -inf" (f16_round_down_mode():
+// MODE.FP_ROUND[3:2] = 2; f32 arithmetic has its own two bits and stays at nearest-even): the conversion is ONE instruction
+// instead of convert-towards-zero, convert back, compare, add.  Bit-equal to f16_down for every float, subnormals and the
+// overflows above included (tests/test_gpu_parity.py::test_threshold_plane_rounding_device_equals_host runs both device forms).
+__device__ __forceinline__ void f16_round_down_mode() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_setreg(1 | (2 << 6) | ((2 - 1) << 11), 2);
+#endif
 }
+__device__ __forceinline__ uint16_t f16_down_mode(float x) {
+    uint32_t h = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_cvt_f16_f32_e32 %0, %1" : "=v"(h) : "v"(x));
+#endif
+    return (uint16_t)h;
+}
+__device__ __forceinline__ uint16_t plane_value_mode(const PlaneParams &p, float Lf) { return f16_down_mode((Lf - 2.0f) * p.inv_S); }
 // C-in of one window from its plane value v (as f32; +inf = never): -floor(S * v).  S * v is exact (S a power of two);
 // +inf comes out as -1e9, an unreachable threshold (|G| < 2^24).  Five instructions: cvt, mul, floor, med3, cvt (negated).
 __host__ __device__ inline int prefilter_cin(float S, float v) {

@@ -103,11 +103,16 @@ extern "C" void focr_debug_f16_down(const float *x, size_t n, uint16_t *out) {
 }
 
 // ... and the device flavour (v_cvt_pkrtz + fix-up), for the GPU test that compares the two bit for bit
-__global__ void f16_down_kernel(const float *__restrict__ x, size_t n, uint16_t *__restrict__ out) {
+__global__ void f16_down_kernel(const float *__restrict__ x, size_t n, uint16_t *__restrict__ out, int mode_form) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f16_down(x[i]);
+    if (mode_form) {  // the statistics kernel's form: the wave's f16 rounding mode set to "towards -inf", one conversion instruction
+        f16_round_down_mode();
+        if (i < n) out[i] = f16_down_mode(x[i]);
+    } else if (i < n) {
+        out[i] = f16_down(x[i]);
+    }
 }
-extern "C" int focr_debug_f16_down_device(focr_ctx_t *c, const float *x, size_t n, uint16_t *out) {
+extern "C" int focr_debug_f16_down_device(focr_ctx_t *c, const float *x, size_t n, uint16_t *out, int mode_form) {
     if (!c || !x || !out || !n) return fail(c, FOCR_ERR_INVALID, "focr_debug_f16_down_device: bad arguments");
     FOCR_HIP(c, hipSetDevice(c->device));
     float *dx = nullptr;
@@ -116,7 +121,7 @@ extern "C" int focr_debug_f16_down_device(focr_ctx_t *c, const float *x, size_t 
         FOCR_HIP(c, hipMalloc((void **)&dx, n * 4));
         FOCR_HIP(c, hipMalloc((void **)&dout, n * 2));
         FOCR_HIP(c, hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(f16_down_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx, n, dout);
+        hipLaunchKernelGGL(f16_down_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx, n, dout, mode_form);
         FOCR_HIP(c, hipGetLastError());
         FOCR_HIP(c, hipMemcpyAsync(out, dout, n * 2, hipMemcpyDeviceToHost, c->stream));
         FOCR_HIP(c, hipStreamSynchronize(c->stream));

@@ -105,7 +105,10 @@ struct StatsOut {  // what a statistics launch writes for one size class
 template <int OUT, typename IDX>
 __device__ __forceinline__ void stats_store(const StatsOut &o, IDX idx, bool emit, float Lf) {
     if (OUT) {
-        reinterpret_cast<uint16_t *>(o.out)[idx] = emit ? plane_value(o.p, Lf) : PLANE_NEVER;
+        // the kernel runs in the "f16 conversions round towards -inf" mode (f16_round_down_mode); a pass's planes span < 4 GiB
+        // (launch_scan_mfma), so the entry's BYTE offset fits 32 bits: uniform base + 32-bit lane offset, no 64-bit vector add per store
+        const uint32_t byte_off = (uint32_t)idx * 2u;
+        *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(o.out) + byte_off) = emit ? plane_value_mode(o.p, Lf) : PLANE_NEVER;
     } else {
         reinterpret_cast<int32_t *>(o.out)[idx] = emit ? threshold_negL(Lf) : -REJECT;
     }
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     // dynamic LDS, sized for this class's n_h (stats_lds_bytes): ~21 KB at n_h = 15 -> 7 blocks per CU; the kernel
     // lives on that occupancy (global-load latency, two barriers per tile)
     extern __shared__ uint32_t stats_lds[];
+    if (OUT) f16_round_down_mode();  // plane values are converted with one instruction each (mfma_common.h)
     const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const uint32_t rows = STY + n_h - 1;
     uint32_t (*tile)[SLDW] = reinterpret_cast<uint32_t (*)[SLDW]>(stats_lds);

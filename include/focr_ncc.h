@@ -394,10 +394,13 @@ int focr_debug_prefilter(const focr_template_t *templates, size_t n_templates, c
                          int column_drop, const uint8_t *windows, size_t n_windows, uint32_t frame_w, uint32_t frame_h,
                          float threshold, double *sim, int64_t *d, double *info, size_t n_info);
 
-/* The threshold planes' directed rounding (f32 -> f16 bits towards -inf, |x| < 65504), host flavour, for the CPU tests. */
+/* The threshold planes' directed rounding (f32 -> f16 bits towards -inf; above the f16 range: the largest finite f16 for
+ * positive values, -inf for negative ones), host flavour, for the CPU tests. */
 void focr_debug_f16_down(const float *x, size_t n, uint16_t *out);
-/* The same rounding as the device performs it (the GPU tests compare the two bit for bit). */
-int focr_debug_f16_down_device(focr_ctx_t *ctx, const float *x, size_t n, uint16_t *out);
+/* The same rounding as the device performs it (the GPU tests compare them bit for bit): mode_form = 0 the generic device
+ * form (convert towards zero + fix-up), 1 the statistics kernel's form (the waves' f16 rounding mode set to "towards -inf",
+ * one conversion instruction). */
+int focr_debug_f16_down_device(focr_ctx_t *ctx, const float *x, size_t n, uint16_t *out, int mode_form);
 
 #ifdef __cplusplus
 }
