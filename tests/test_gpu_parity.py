@@ -834,6 +834,18 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
         offsets, m = sc.matches()
         _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[0], "batch that was not announced")
         pipe.release(t)
+        # a larger batch announced to a lane whose staging buffer is too small for it: the buffer grows behind the lane's last ingest
+        big = PinnedPages(3, 128, 336)
+        pins.append(big)
+        for p in range(3):
+            big.array[p] = synth_page(bank_x2, SYNTH_SEED_BASE + 1400 + p, 336, 128)
+        pipe.prefetch(big.array)
+        t = pipe.submit(big.array, 0.8)
+        sc = pipe.wait(t)
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 3, len(bank_x2)), _oracle_lists(big.array, bank_x2, 0.8, 1024), "larger announced batch")
+        pipe.release(t)
+        pipe.prefetch(pins[1].array)  # an announcement that is never submitted: destroying the pipe must cope
     finally:
         pipe.close()
         for pin in pins:
