@@ -786,6 +786,13 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
     const unsigned cus = c->n_cus;
     uint32_t *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
     const TailWork tw{c->d_counter + TAIL_DONE_WORD, n_rows, hbase, c->d_res + 6, c->d_res + 5};  // the verify's last workgroup does the prefix
+    // The verify's workgroups are persistent (they walk the list with the grid's stride), so where the scan kernel is confined to
+    // scan_cus CUs — several batches in flight — the verify asks for no more workgroups than fit the CUs the scan leaves free: a
+    // verify launched in the gap between two scan launches would otherwise put a workgroup on every CU of the chip and hold it
+    // until the kernel ends, and the next scan launch's workgroups wait for whole CUs (C2, three in flight, one box, alternating:
+    // 512 workgroups 32.55 Gpx/s · 64: 32.82 · 32: 31.2 with the scan launch at 1.57 instead of 1.68 ms, but the lane then waits
+    // for its verify).  The whole-bank-in-LDS forms only: the chunked verify of large banks keeps the chip (below).
+    const unsigned vcus = (c->scan_cus && c->scan_cus < cus) ? std::max(cus - c->scan_cus, cus / 16) : cus;
     if (ub_c) {
         const VerifyArgs va = verify_args(c, thr_d);
         size_t lds;
@@ -821,6 +828,8 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
                 ct.t_lo[ct.n] = (uint32_t)c->n_templates;
                 ct.row_lo[ct.n] = c->h_vrow0_t[c->n_templates];
                 const size_t lds_c = (size_t)ct.max_templates * sizeof(VerifyMeta) + (((size_t)ct.max_rows * (c->vrow_bytes / 4) + 3) & ~(size_t)3) * 4 + queue_bytes;
+                // one workgroup per CU of the whole chip: at configs[2] the chunk passes are a fifth of a lane's chain, and the lane
+                // waits for them (half / a third / a quarter of the CUs: 7.25 / 7.21 / 7.12 Gpx/s against 7.28)
                 const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
 #define FOCR_VERIFY_CHUNKS(R)                                                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_chunks_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);                 \
@@ -837,7 +846,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
             }
         }
         const unsigned per_cu = mode == 2 ? 2u : (mode == 0 && c->n_templates * sizeof(VerifyMeta) <= ((size_t)64 << 10) ? 2u : 1u);
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus * per_cu));
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)vcus * per_cu));
 #define FOCR_VERIFY_LIST(M)                                                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_list_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL(verify_list_kernel<M>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
@@ -870,7 +879,7 @@ int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, si
     const unsigned cus = c->n_cus;
     const uint32_t *hits = (const uint32_t *)c->rows_hits.p, *hbase = (const uint32_t *)c->rows_hbase.p;
     if (ub_c) {
-        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16);
+        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16));
         hipLaunchKernelGGL(hit_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, c->row_hist, hbase,
                            (const float *)c->scan_pos.p, (const uint32_t *)c->scan_flags.p, c->d_hit_keys, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
         FOCR_HIP(c, hipGetLastError());
