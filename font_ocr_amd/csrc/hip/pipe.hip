@@ -123,8 +123,11 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
             bool prefetched = false;
             {
                 std::lock_guard<std::mutex> lk(L->mu);
-                prefetched = !job.on_device && L->pf_ptr == job.pages && L->pf_bytes == job.n_pages * job.r_w * job.r_h;
+                const bool announced = !job.on_device && L->pf_ptr == job.pages;
+                prefetched = announced && rc == FOCR_OK && L->pf_bytes == job.n_pages * job.r_w * job.r_h;
+                if (announced && !prefetched) L->pf_ptr = nullptr;  // announced with another geometry (or the batch failed already): the announcement is void
             }
+            if (!prefetched) L->cv.notify_all();
             if (rc == FOCR_OK && prefetched) {  // the pages are already in the lane's staging buffer (or on their way): no copy on this stream
                 hipError_t e = hipStreamWaitEvent(c->stream, L->ev_prefetch, 0);
                 if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: prefetch wait failed: ") + hipGetErrorString(e));

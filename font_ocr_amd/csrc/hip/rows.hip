@@ -127,11 +127,9 @@ struct TailWork {
 };
 __device__ __forceinline__ bool last_workgroup(uint32_t *done) {
     __shared__ uint32_t is_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every thread's own stores, before the workgroup reports in
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (is_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
