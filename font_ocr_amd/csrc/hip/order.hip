@@ -382,9 +382,11 @@ __global__ __launch_bounds__(1024) void unit_prefix_kernel(uint32_t T, uint32_t 
             seg_count[s] = min(run, cap);  // the reference stops the call at n_out matches (src/ncc.cpp:225-227)
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every thread's own stores, before the workgroup reports in
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();  // the workgroup's stores are in this XCD's L2; one agent-scope release per workgroup writes them back (rows.hip, last_workgroup)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
     __syncthreads();
     if (is_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

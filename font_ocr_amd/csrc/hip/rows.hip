@@ -127,9 +127,13 @@ struct TailWork {
 };
 __device__ __forceinline__ bool last_workgroup(uint32_t *done) {
     __shared__ uint32_t is_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every thread's own stores, before the workgroup reports in
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();  // the workgroup's stores have left its waves (workgroup-scope release: they are in this XCD's L2) ...
+    if (threadIdx.x == 0) {
+        // ... and ONE agent-scope release writes that L2's dirty lines back for the other XCDs (a workgroup lives on one XCD).  Not one
+        // per thread: 8 192 L2 write-backs per launch instead of 512 doubled the verify's time alone on the chip (183 -> 383 us).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        is_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
     __syncthreads();
     if (is_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

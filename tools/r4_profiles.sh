@@ -30,7 +30,7 @@ bash tools/timeline.sh > $out/timeline_bench_c2.log 2>&1; say "timeline done"
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/tmp_e2e -o t -- python3 $repo/tools/e2e_leg.py --steps 120 > $out/e2e_traced_run.json 2> $out/e2e_traced.err)
 for k in kernel_trace memory_copy_trace; do f=$(find $out/tmp_e2e -name "*${k}.csv" | head -1); [ -n "$f" ] && cp $f $out/e2e_${k}.csv; done; rm -rf $out/tmp_e2e
 python3 tools/e2e_timeline.py $out/e2e_kernel_trace.csv $out/e2e_memory_copy_trace.csv > $out/e2e_timeline.log 2>&1; rm -f $out/e2e_kernel_trace.csv $out/e2e_memory_copy_trace.csv; say "e2e timeline done"
-for v in "" "--no-prefetch" "--resident"; do python3 tools/e2e_leg.py --steps 200 $v >> $out/e2e_legs.jsonl 2>/dev/null; done; say "e2e legs: $(cat $out/e2e_legs.jsonl | tr '\n' ' ')"
+rm -f $out/e2e_legs.jsonl $out/bench_thr_sweep.log; for v in "" "--no-prefetch" "--resident"; do python3 tools/e2e_leg.py --steps 200 $v >> $out/e2e_legs.jsonl 2>/dev/null; done; say "e2e legs: $(cat $out/e2e_legs.jsonl | tr '\n' ' ')"
 # threshold sweep: value, scan ms, candidates, hits, redone batches
 for thr in 0.5 0.8 0.9 0.97; do
 python3 bench.py --no-cpu-baseline --no-e2e --steps 100 --threshold $thr 2>/dev/null | python3 -c "
