@@ -257,7 +257,8 @@ int focr_ctx_set_row_tail(focr_ctx_t *ctx, int mode);
 int focr_ctx_set_size_estimates(focr_ctx_t *ctx, int on);
 /* How the size estimates have fared on this context: batches redone with exact sizes because a count exceeded its bound
  * (since the context was created), the margin the next estimated scan would add to the last counts (0.04 .. 0.2), and the
- * largest page row (candidates) of the last scan that took the row tail (0: it took the legacy tail).  Any pointer may
+ * largest bucket of the last scan that took a row tail (hits of a page row / x-segment with the hits-first tail, candidates with round
+ * 3's; 0: it took the legacy tail).  Any pointer may
  * be NULL. */
 int focr_size_estimate_stats(focr_ctx_t *ctx, uint64_t *redone, double *margin, uint32_t *row_max);
 
