@@ -984,6 +984,45 @@ def test_size_estimates_and_redo_on_overflow(bank_x2, mode):
         assert sc.lines_flat().tobytes() == lines_a.tobytes()
 
 
+def test_unexpected_large_bucket_under_estimated_sizes_redoes_the_batch():
+    """Round 4: the second sort launch (buckets above 1 024 hits) exists only where such a bucket is expected.  Two batches of one
+    setup with the SAME number of hits within the estimates' margin — the first spreads them over every page row (largest bucket
+    ~ 500), the second packs them into a few rows (> 1 024 each): no count exceeds its bound, the bucket does, the batch is redone
+    with exact sizes and the lists equal the reference's."""
+    rng = np.random.default_rng(77)
+    bank = _random_bank(rng, [(8, 15)], 40)
+    r_w, r_h = 180, 96
+    noise = rng.integers(0, 256, (2, r_h, r_w), dtype=np.uint8)
+    spread = np.full((2, r_h, r_w), 255, np.uint8)
+    spread[:, :, 20:64] = noise[:, :, 20:64]          # a noise strip through every row: few windows per row
+    packed = np.full((2, r_h, r_w), 255, np.uint8)
+    packed[:, 30:38, :] = noise[:, 30:38, :]           # full-width noise in a band of rows: many windows in few rows
+    thr = 0.02                                         # noise against noise: about four windows in ten pass
+    cap = 4096  # never reached: ~1 400 hits per (page, template)
+    want = {"spread": _oracle_lists(spread, bank, thr, cap), "packed": _oracle_lists(packed, bank, thr, cap)}
+    n = {k: sum(len(x) for p in v for x in p) for k, v in want.items()}
+    rows = {k: max(int(np.bincount(np.concatenate([x["y"] for x in p if len(x)]).astype(np.int64)).max()) for p in v) for k, v in want.items()}
+    assert rows["spread"] < 800 and rows["packed"] > 1100, rows          # largest bucket = hits of one page row
+    assert n["packed"] < 1.15 * n["spread"] + 8000, n                    # inside the estimates' margin: only the bucket overflows
+    with Scanner(0) as sc:
+        sc.set_bank(bank)
+        sc.set_pages(spread)
+        sc.scan(thr, cap, MFMA1)   # exact sizes
+        sc.scan(thr, cap, MFMA1)   # estimated
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want["spread"], "spread")
+        redone0 = sc.size_estimate_stats()["redone"]
+        sc.upload_pages(packed, 0)
+        sc.scan(thr, cap, MFMA1)   # estimated from the spread batch: no second sort launch planned
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want["packed"], "packed")
+        assert sc.size_estimate_stats()["redone"] == redone0 + 1
+        sc.scan(thr, cap, MFMA1)   # now the large bucket is expected: estimated sizes, second launch, nothing redone
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want["packed"], "packed again")
+        assert sc.size_estimate_stats()["redone"] == redone0 + 1
+
+
 def test_compat_symbols_in_the_reference_call_pattern(bank_x2):
     """The unmodified reference host calls ncc_8_u8 / ncc_16_u8 once per template with the same page and, per size class,
     the same window tables (src/ncc.rs:332-404, 587-701).  All 380 calls of one 608x720 page through the drop-in symbols:
