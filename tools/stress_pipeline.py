@@ -2,7 +2,7 @@
 estimated sizes and the scans taking turns, every batch's matches and lines compared with the direct (v_dot4, no prefilter,
 no item queue) scan of the same pages on a fourth context.
 
-    python tools/stress_pipeline.py [--batches 120] [--pages 24] [--w 608] [--h 240]
+    python tools/stress_pipeline.py [--batches 120] [--pages 24] [--w 608] [--h 240] [--bank x2|x2y2]
 """
 import argparse, os, sys, time
 import numpy as np
@@ -15,9 +15,10 @@ ap.add_argument("--batches", type=int, default=120)
 ap.add_argument("--pages", type=int, default=24)
 ap.add_argument("--w", type=int, default=608)
 ap.add_argument("--h", type=int, default=240)
+ap.add_argument("--bank", choices=["x2", "x2y2"], default="x2", help="x2y2 = BASELINE configs[2]'s 1 520 templates: the verify runs in chunk passes")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-bank = Bank.load(os.path.join(ROOT, "tests/golden/bank_dejavu13_ascii95_x2.bin"))
+bank = Bank.load(os.path.join(ROOT, f"tests/golden/bank_dejavu13_ascii95_{a.bank}.bin"))
 rng = np.random.default_rng(7)
 pipe = Pipeline(0, 3); pipe.set_bank(bank)
 ref = Scanner(0); ref.set_bank(bank)
