@@ -17,8 +17,10 @@ if os.environ.get("KB_SCAN_CUS"): sc.set_scan_cus(int(os.environ["KB_SCAN_CUS"])
 for _ in range(2): sc.scan(0.8, 1024, SCAN_MFMA)
 acc = {}
 N = 5
+POST = bool(os.environ.get("KB_POST"))  # also focr_process_hits(0.95, 5), as a bench step does
 for _ in range(N):
     sc.scan(0.8, 1024, SCAN_MFMA)
+    if POST: sc.process_hits(0.95, 5)
     for li in sc.launches(): acc[li["name"]] = acc.get(li["name"], 0) + li["ms"] / N
 t = sc.timings(); c = sc.counters()
 print("prefilter", os.environ.get("KB_PREFILTER", "0"), {k: round(v, 3) for k, v in acc.items()}, {k: round(v, 3) for k, v in t.items()}, c["candidates"], c["raw_hits"])
