@@ -645,11 +645,13 @@ def main():
             run_step(sc)
         fence()
         e2e = total_px / (time.perf_counter() - t1) / 1e6
-    if not args.no_e2e and shard is None and not use_dist:
-        # SURVEY.md section 8(d) asks for both timings: device-resident (`value`) and end to end.  A short extra leg outside the
-        # timed region: every step starts from PAGE-LOCKED HOST memory; the same contexts / host threads as the headline run,
-        # each uploading its batch (one asynchronous DMA + inversion kernel on its stream) before scanning it, so batch k+1's
-        # copy crosses PCIe under batch k's scan.  Never the headline value.
+    leg_errors = {}  # an optional leg (PCIe-inclusive rate, isolated kernel, CPU baseline) that fails must not take the headline line with it
+
+    def measure_e2e():
+        """SURVEY.md section 8(d) asks for both timings: device-resident (`value`) and end to end.  A short extra leg outside the
+        timed region: every step starts from PAGE-LOCKED HOST memory; the same contexts / host threads as the headline run; batch
+        k + n_ctx is announced (focr_pipe_prefetch: its DMA starts on a copy stream of its lane) right after batch k is submitted, so
+        every copy crosses PCIe under the scans of the batches in flight.  Never the headline value."""
         from font_ocr_amd.searcher import PinnedPages
 
         pins = []
@@ -660,7 +662,7 @@ def main():
 
         def pipe_steps(n):
             tickets = deque()
-            ahead = min(n_ctx, n)  # batch k + n_ctx is announced (its DMA started: focr_pipe_prefetch) right after batch k is submitted
+            ahead = min(n_ctx, n)
             for k in range(ahead):
                 pipe.prefetch(pins[k % n_ctx].array)
             for k in range(n):
@@ -678,28 +680,40 @@ def main():
 
         pipe_steps(2 * n_ctx)
         fence()
-        e2e_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 120))  # 0.2 s: fill + drain of the pipeline are 2-3 % of it
+        n_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 120))  # 0.2 s: fill + drain of the pipeline are 2-3 % of it
         t1 = time.perf_counter()
-        pipe_steps(e2e_steps)
+        pipe_steps(n_steps)
         fence()
-        e2e_pipe = P * R_W * R_H * e2e_steps / (time.perf_counter() - t1) / 1e6
+        rate = P * R_W * R_H * n_steps / (time.perf_counter() - t1) / 1e6
         for pin in pins:
             pin.close()
+        return rate, n_steps
+
+    if not args.no_e2e and shard is None and not use_dist:
+        try:
+            e2e_pipe, e2e_steps = measure_e2e()
+        except Exception as e:  # noqa: BLE001 - reported in the line; the device-resident measurement stands
+            leg_errors["e2e_value_incl_h2d_pipelined"] = repr(e)
+            e2e_pipe = None
     counters = sc.counters()
 
     # the dominant kernel alone on the chip (no other batch in flight, all CUs): a short extra leg outside the timed
     # region, reported beside the in-flight figure so that both ways of reading "kernel duration" are on the table
     iso = {}
-    if rank == 0 and n_ctx > 1:
-        sc.set_scan_cus(0)
-        for i in range(14):  # 4 to settle (the leg starts from an idle GPU), 10 measured
-            run_step(sc)
-            if i >= 4:
-                for li in sc.launches():
-                    k = iso.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0))
-                    k["ms"] += li["ms"]
-                    k["n"] += 1
-        sc.set_scan_cus(scan_cus)
+    if rank == 0 and n_ctx > 1 and not leg_errors:  # (a failed PCIe leg leaves the lanes in an unknown state)
+        try:
+            sc.set_scan_cus(0)
+            for i in range(14):  # 4 to settle (the leg starts from an idle GPU), 10 measured
+                run_step(sc)
+                if i >= 4:
+                    for li in sc.launches():
+                        k = iso.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0))
+                        k["ms"] += li["ms"]
+                        k["n"] += 1
+            sc.set_scan_cus(scan_cus)
+        except Exception as e:  # noqa: BLE001
+            leg_errors["frac_isolated"] = repr(e)
+            iso = {}
 
     if trace_on and rank == 0:
         t_lo, t_hi = (t0 - t_trace0) * 1e6, (t0 + dt - t_trace0) * 1e6
@@ -818,29 +832,32 @@ def main():
         out["work"] = {"candidates": counters["candidates"], "raw_hits": counters["raw_hits"], "chars_out": int(n_chars)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O  # test infrastructure: the CPU baseline leg is allowed to use it
+        try:
+            from oracle import oracle as O  # test infrastructure: the CPU baseline leg is allowed to use it
 
-        threads = min(effective_cpus(), 32)
-        S = args.cpu_sample_pages or min(P, 4 * threads)
-        inv = (255 - pages[:S]).astype(np.uint8)
-        use_ref = O.have_ref()
-        passes = 2  # ~15 s of CPU work on the GPU box's 32 threads
-        t0 = time.perf_counter()
-        for _ in range(passes):
-            total, cpu_counts, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
-        cdt = (time.perf_counter() - t0) / passes
-        t0 = time.perf_counter()
-        O.scan_pages_mt(inv[:2], bank, args.threshold, 1024, use_ref=use_ref, threads=1)  # single-core figure, 2 pages
-        cdt1 = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": round(S * R_W * R_H / cdt / 1e6, 4),
-            "unit": "Mpx/s",
-            "cores": threads,
-            "kind": "reference" if use_ref else "port",
-            "sample": f"{S} of the same synthetic pages x {len(bank)} templates, {passes} passes, one page per thread "
-                      f"(window tables + kernel calls as src/ncc.rs:231-404), {cdt * passes:.1f} s wall, {int(total)} raw hits per pass",
-            "value_1_core": round(2 * R_W * R_H / cdt1 / 1e6, 4),
-        }
+            threads = min(effective_cpus(), 32)
+            S = args.cpu_sample_pages or min(P, 4 * threads)
+            inv = (255 - pages[:S]).astype(np.uint8)
+            use_ref = O.have_ref()
+            passes = 2  # ~15 s of CPU work on the GPU box's 32 threads
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                total, cpu_counts, _ = O.scan_pages_mt(inv, bank, args.threshold, 1024, use_ref=use_ref, threads=threads)
+            cdt = (time.perf_counter() - t0) / passes
+            t0 = time.perf_counter()
+            O.scan_pages_mt(inv[:2], bank, args.threshold, 1024, use_ref=use_ref, threads=1)  # single-core figure, 2 pages
+            cdt1 = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(S * R_W * R_H / cdt / 1e6, 4),
+                "unit": "Mpx/s",
+                "cores": threads,
+                "kind": "reference" if use_ref else "port",
+                "sample": f"{S} of the same synthetic pages x {len(bank)} templates, {passes} passes, one page per thread "
+                          f"(window tables + kernel calls as src/ncc.rs:231-404), {cdt * passes:.1f} s wall, {int(total)} raw hits per pass",
+                "value_1_core": round(2 * R_W * R_H / cdt1 / 1e6, 4),
+            }
+        except Exception as e:  # noqa: BLE001 - the reference's CPU rate is a reported baseline, not the measurement
+            leg_errors["cpu_baseline"] = repr(e)
 
     if rank == 0 and args.config in ("c2", "c4") and not args.noise and first_page_is_seed0:
         # parity in the same run: page 0 of this very batch against the committed reference golden (tests/golden/c2_page0.npz)
@@ -862,6 +879,8 @@ def main():
         except OSError:
             out["parity"] = "golden fixture not found"
 
+    if leg_errors:
+        out["optional_leg_errors"] = leg_errors
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     pipe.close()
