@@ -93,7 +93,7 @@ def self_launch(args):
         import torch  # counting devices does not initialise the GPU
 
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (os.environ.get("FOCR_BENCH_SHARE_GPU") and have >= 1):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine shows {have} GPU(s); refusing to measure fewer GPUs than asked for\n")
             return 2
     store_dir = tempfile.mkdtemp(prefix="focr_bench_")
@@ -312,6 +312,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FOCR_BENCH_SHARE_GPU=1: a REHEARSAL of the N-rank protocol on a one-GPU box — every rank uses device 0 (the line says so and
+    # is never a scaling measurement: the ranks share one chip)
+    share_gpu = bool(os.environ.get("FOCR_BENCH_SHARE_GPU")) and world > 1
+    if share_gpu:
+        local_rank = 0
     if world != args.gpus:  # never measure another number of GPUs than the one asked for
         os.write(2, f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n".encode())
         raise SystemExit(2)
@@ -338,7 +343,11 @@ def main():
             pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         except Exception:  # noqa: BLE001 - an older torch: default priority
             pg_opts = None
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts, **rendezvous_kwargs())
+        if share_gpu:  # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the rehearsal's collectives run over gloo on host tensors
+            dist.init_process_group("gloo", rank=rank, world_size=world, **rendezvous_kwargs())
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=pg_opts, **rendezvous_kwargs())
+    coll_dev = torch.device("cpu") if share_gpu else dev  # where the collectives' tensors live
 
     mode = SCAN_MFMA if args.mode == "mfma" else SCAN_DIRECT
     global R_W, R_H
@@ -456,7 +465,7 @@ def main():
     def gather_worker():
         torch.cuda.set_device(local_rank)  # the current device is per thread
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))  # off the legacy null stream; high priority, as RCCL's
-        gather = CharGather(rank, world, dev, capacity=slot_bytes)  # every buffer of the exchange allocated once
+        gather = CharGather(rank, world, coll_dev, capacity=slot_bytes)  # every buffer of the exchange allocated once
         pending = []
         while True:
             item = gather_q.get()
@@ -594,7 +603,7 @@ def main():
         fence()
         go = time.perf_counter() - t_settle < args.settle_s
         if use_dist and world > 1:  # every rank must run the same number of rounds: each one ends in collectives (fence)
-            flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+            flag = torch.tensor([1 if go else 0], device=coll_dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go = bool(flag.item())
     if gc_mode == "freeze":
@@ -617,10 +626,10 @@ def main():
     dt_local = dt_own
     ranks_seen, per_rank = 1, None
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        seen = torch.tensor([1], device=dev, dtype=torch.int64)  # rank census over the nccl group: the line is for exactly this many GPUs
+        seen = torch.tensor([1], device=coll_dev, dtype=torch.int64)  # rank census over the nccl group: the line is for exactly this many GPUs
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         ranks_seen = int(seen.item())
 
@@ -628,8 +637,8 @@ def main():
     value = total_px / dt / 1e6
     if use_dist:  # every rank's own rate (its pages over its own time)
         my_pages = (n_mine if shard is not None else P) * args.steps
-        mine = torch.tensor([my_pages * R_W * R_H / dt_local / 1e6], device=dev, dtype=torch.float64)
-        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        mine = torch.tensor([my_pages * R_W * R_H / dt_local / 1e6], device=coll_dev, dtype=torch.float64)
+        every = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [round(float(v.item()), 2) for v in every]
     # what the size estimates did during the timed region: the bench rescans the same resident batches every step, so the
@@ -766,7 +775,8 @@ def main():
             "prefilter": args.prefilter,
             "column_drop": not args.no_column_drop,
             "tail": {"hits": "hits-first rows", "rows3": "round-3 rows", "legacy": "legacy radix sort"}[args.tail],
-            "parallelism": f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU",
+            "parallelism": (f"REHEARSAL: {world} ranks on one GPU, gloo gather of match lists" if share_gpu else
+                            f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU"),
         },
     }
     if e2e is not None:
@@ -881,6 +891,8 @@ def main():
 
     if leg_errors:
         out["optional_leg_errors"] = leg_errors
+    if share_gpu:
+        out["rehearsal"] = f"FOCR_BENCH_SHARE_GPU: all {world} ranks on ONE GPU — the launcher, the barriers, the sharding and the gather of the N-rank run on real hardware; not a scaling measurement"
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     pipe.close()

@@ -74,7 +74,7 @@ class CharGather:
         self.k += 1
         buf = self.buf[s][:mx]
         if m:
-            buf[:m].copy_(mine, non_blocking=True)
+            buf[:m].copy_(mine, non_blocking=self.cuda)  # (gloo: the exchange reads host memory, so a device source is copied synchronously)
         out = [o[:mx] for o in self.out[s]] if self.rank == 0 else None
         work = dist.gather(buf, out, dst=0, async_op=async_op)
 
