@@ -185,7 +185,7 @@ def rendezvous_kwargs():
     fails (and with it the run, see self_launch) instead of waiting for the backend's default of many minutes."""
     import datetime
 
-    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("FOCR_BENCH_INIT_TIMEOUT", "180")))}
+    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("FOCR_BENCH_INIT_TIMEOUT", "300")))}
     if os.environ.get("FOCR_BENCH_INIT"):
         kw["init_method"] = os.environ["FOCR_BENCH_INIT"]
     else:
