@@ -218,6 +218,12 @@ struct focr_ctx {
                                     // written at ingest so that the scan kernels need no v_xor per fragment dword
     uint8_t *d_stage = nullptr;  // device staging for uploads
     size_t stage_bytes = 0;
+    // the executor's second page set (pipe.hip, focr_pipe_prefetch): the NEXT batch of a lane is ingested here, on the lane's copy
+    // stream, while the lane still scans d_pages; the two sets change places when that batch starts (pages_alt_swap, ctx.hip)
+    struct PageSet {
+        uint8_t *u8 = nullptr, *i8 = nullptr;
+        size_t capacity = 0, r_w = 0, r_h = 0, pitch = 0, rows_alloc = 0;
+    } alt;
 
     // scan results
     size_t sub_p0 = 0, sub_np = 0;  // page range the scan pipeline is currently working on (normally the whole batch)
@@ -315,6 +321,8 @@ int build_mfma_bank(focr_ctx *ctx, const uint8_t *needles);
 void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
                        std::vector<uint32_t> &direct, std::vector<uint8_t> &dense);
 void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layouts, bank offsets (host only)
+int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s);  // ctx.hip
+int pages_alt_swap(focr_ctx *c, size_t n_pages, size_t r_w, size_t r_h);
 int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of);  // host only
 
 // ---- device helpers: the reference's f64 epilogue, operation for operation ----

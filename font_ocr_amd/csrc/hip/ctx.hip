@@ -269,6 +269,8 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     free_results(c);
     free_dev(c->d_pages);
     free_dev(c->d_pages_i8);
+    free_dev(c->alt.u8);
+    free_dev(c->alt.i8);
     free_dev(c->d_stage);
     free_dev(c->d_counter);
     free_dev(c->d_res);
@@ -496,6 +498,77 @@ static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count,
     c->sizes_pending = c->post_pending = false;  // results of the previous batch are gone with its pages
     return FOCR_OK;
 }
+
+}  // extern "C"
+
+namespace focr {
+
+// The executor's early ingest (pipe.hip): n_pages tight luma8 pages at d_luma (device memory) become the ALTERNATE page set of the
+// context, on stream s — not the context's own: the context may be scanning d_pages meanwhile.  The caller orders s behind the
+// arrival of d_luma and the context's stream behind s (an event) before pages_alt_swap makes the set current.  The alternate set
+// is free whenever this is called: it was current two batches ago, and every batch of a lane ends with focr_sync.
+int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s) {
+    if (!c || !d_luma || !n_pages || !r_w || !r_h || r_w > 65535 || r_h > 65535 || n_pages > 65535)
+        return fail(c, FOCR_ERR_INVALID, "pages_alt_ingest: bad arguments");
+    focr_ctx::PageSet &a = c->alt;
+    if (!a.u8 || a.r_w != r_w || a.r_h != r_h || a.capacity < n_pages) {
+        free_dev(a.u8);  // (hipFree waits for the device: a change of geometry, not the steady state)
+        free_dev(a.i8);
+        a = focr_ctx::PageSet{};
+        const size_t pitch = (r_w + 64 + 63) / 64 * 64, rows_alloc = r_h + 48;  // as focr_pages_alloc
+        const size_t bytes = n_pages * rows_alloc * pitch;
+        if (hipMalloc(&a.u8, bytes) != hipSuccess || hipMalloc(&a.i8, bytes) != hipSuccess) {
+            free_dev(a.u8);
+            free_dev(a.i8);
+            return fail(c, FOCR_ERR_NOMEM, "pages_alt_ingest: hipMalloc failed");
+        }
+        a.capacity = n_pages;
+        a.r_w = r_w;
+        a.r_h = r_h;
+        a.pitch = pitch;
+        a.rows_alloc = rows_alloc;
+        FOCR_HIP(c, hipMemsetAsync(a.u8, 0, bytes, s));
+        FOCR_HIP(c, hipMemsetAsync(a.i8, 0x80, bytes, s));  // paper (0) as int8
+    }
+    const size_t n_rows = n_pages * r_h;
+    const unsigned blocks = (unsigned)std::min<size_t>(n_rows, (size_t)1 << 20);
+    const int dwords = r_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_luma) & 3) == 0;
+    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(64), 0, s, (const uint8_t *)d_luma, a.u8, a.i8, (uint32_t)r_w, (uint32_t)r_h, a.pitch, a.rows_alloc, (size_t)0,
+                       n_rows, invert, dwords);
+    FOCR_HIP(c, hipGetLastError());
+    return FOCR_OK;
+}
+
+// The alternate set becomes the context's pages (n_pages of r_w x r_h, as ingested by pages_alt_ingest), the previous pages the
+// alternate set.  Host state only: the caller has ordered the context's stream behind the ingest.
+int pages_alt_swap(focr_ctx *c, size_t n_pages, size_t r_w, size_t r_h) {
+    focr_ctx::PageSet &a = c->alt;
+    if (!a.u8 || a.r_w != r_w || a.r_h != r_h || a.capacity < n_pages) return fail(c, FOCR_ERR_STATE, "pages_alt_swap: no such alternate page set");
+    focr_ctx::PageSet cur;
+    cur.u8 = c->d_pages;
+    cur.i8 = c->d_pages_i8;
+    cur.capacity = c->pages_capacity;
+    cur.r_w = c->r_w;
+    cur.r_h = c->r_h;
+    cur.pitch = c->pitch;
+    cur.rows_alloc = c->rows_alloc;
+    c->d_pages = a.u8;
+    c->d_pages_i8 = a.i8;
+    c->pages_capacity = a.capacity;
+    c->r_w = a.r_w;
+    c->r_h = a.r_h;
+    c->pitch = a.pitch;
+    c->rows_alloc = a.rows_alloc;
+    c->n_pages = n_pages;
+    a = cur;
+    c->scanned = c->processed = false;
+    c->sizes_pending = c->post_pending = false;  // results of the previous batch are gone with its pages
+    return FOCR_OK;
+}
+
+}  // namespace focr
+
+extern "C" {
 
 int focr_pages_upload(focr_ctx_t *c, size_t first, size_t count, const uint8_t *luma, int invert) {
     if (!c || !luma) return fail(c, FOCR_ERR_INVALID, "focr_pages_upload: bad arguments");

@@ -63,15 +63,16 @@ struct PipeLane {
     PipeJob job;
     int rc = FOCR_OK;
     bool stop = false;
-    // focr_pipe_prefetch: the NEXT batch's host pages cross PCIe into a staging buffer of the lane's own, on a copy stream,
-    // while the lane still works on its current batch; the lane's ingest then reads them from there
+    // focr_pipe_prefetch: the NEXT batch's host pages cross PCIe into a staging buffer of the lane's own and are ingested into the
+    // context's ALTERNATE page set (pages_alt_ingest, ctx.hip), both on a copy stream, while the lane still works on its current
+    // batch; when the announced batch starts, the two page sets change places
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_prefetch = nullptr, ev_ingest = nullptr;  // copy done / the ingest that read the staging buffer done
+    hipEvent_t ev_prefetch = nullptr;  // copy + ingest done
     void *pf_stage = nullptr;
     size_t pf_stage_bytes = 0;
     const void *pf_ptr = nullptr;  // host pages announced and on their way (consumed by the submit that brings the same pointer)
-    size_t pf_bytes = 0;
-    bool pf_ingest_recorded = false;  // ev_ingest has been recorded at least once
+    size_t pf_n = 0, pf_w = 0, pf_h = 0;
+    int pf_invert = 0;
 };
 
 }  // namespace focr
@@ -119,29 +120,28 @@ static void lane_main(PipeLane *L, const focr_pipe *P) {
         PipeTrace tr{ticket, 0, P->now_us(), 0, 0, 0, 0};
         int rc = FOCR_OK;
         if (job.pages) {
-            rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
             bool prefetched = false;
             {
                 std::lock_guard<std::mutex> lk(L->mu);
                 const bool announced = !job.on_device && L->pf_ptr == job.pages;
-                prefetched = announced && rc == FOCR_OK && L->pf_bytes == job.n_pages * job.r_w * job.r_h;
-                if (announced && !prefetched) L->pf_ptr = nullptr;  // announced with another geometry (or the batch failed already): the announcement is void
+                prefetched = announced && L->pf_n == job.n_pages && L->pf_w == job.r_w && L->pf_h == job.r_h && L->pf_invert == job.invert;
+                // (announced with another geometry or inversion: the announcement is void and the lane uploads the batch itself)
             }
-            if (!prefetched) L->cv.notify_all();
-            if (rc == FOCR_OK && prefetched) {  // the pages are already in the lane's staging buffer (or on their way): no copy on this stream
+            if (prefetched) {  // the pages are in the context's alternate page set already (or on their way): no copy, no ingest on this stream
                 hipError_t e = hipStreamWaitEvent(c->stream, L->ev_prefetch, 0);
                 if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: prefetch wait failed: ") + hipGetErrorString(e));
-                if (rc == FOCR_OK) rc = focr_pages_upload_device(c, 0, job.n_pages, L->pf_stage, job.invert);
-                if (rc == FOCR_OK && hipEventRecord(L->ev_ingest, c->stream) != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, "focr_pipe: hipEventRecord failed");
-                {
-                    std::lock_guard<std::mutex> lk(L->mu);
-                    L->pf_ptr = nullptr;  // the staging buffer may take the next announcement (behind ev_ingest on the device)
-                    L->pf_ingest_recorded = true;
-                }
-                L->cv.notify_all();
-            } else if (rc == FOCR_OK) {
-                rc = job.on_device ? focr_pages_upload_device(c, 0, job.n_pages, job.pages, job.invert)
-                                   : focr_pages_upload(c, 0, job.n_pages, (const uint8_t *)job.pages, job.invert);
+                if (rc == FOCR_OK) rc = pages_alt_swap(c, job.n_pages, job.r_w, job.r_h);
+            }
+            {
+                std::lock_guard<std::mutex> lk(L->mu);
+                if (L->pf_ptr == job.pages && !job.on_device) L->pf_ptr = nullptr;  // consumed (or void): the lane may take its next announcement
+            }
+            L->cv.notify_all();
+            if (!prefetched) {
+                rc = focr_pages_alloc(c, job.n_pages, job.r_w, job.r_h);
+                if (rc == FOCR_OK)
+                    rc = job.on_device ? focr_pages_upload_device(c, 0, job.n_pages, job.pages, job.invert)
+                                       : focr_pages_upload(c, 0, job.n_pages, (const uint8_t *)job.pages, job.invert);
             }
         }
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
@@ -256,7 +256,6 @@ void focr_pipe_destroy(focr_pipe_t *p) {
             (void)hipStreamDestroy(L->copy_stream);
         }
         if (L->ev_prefetch) (void)hipEventDestroy(L->ev_prefetch);
-        if (L->ev_ingest) (void)hipEventDestroy(L->ev_ingest);
         if (L->pf_stage) (void)hipFree(L->pf_stage);
         for (PinBuf *b : {&L->h_counts, &L->h_page_off, &L->h_line_off, &L->h_chars}) b->release();
         focr_ctx_destroy(L->ctx);
@@ -327,7 +326,7 @@ int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, siz
     return FOCR_OK;
 }
 
-int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t r_w, size_t r_h) {
+int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t r_w, size_t r_h, int invert) {
     if (!p || !pages || !n_pages || !r_w || !r_h) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_prefetch: bad arguments");
     std::lock_guard<std::mutex> plk(p->mu);  // announcements and submits are serialised
     if (p->announced >= p->lanes.size()) return fail(nullptr, FOCR_ERR_STATE, "focr_pipe_prefetch: every lane already holds an announced batch");
@@ -336,26 +335,31 @@ int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t
     const size_t bytes = n_pages * r_w * r_h;
     FOCR_HIP(c, hipSetDevice(c->device));
     std::unique_lock<std::mutex> lk(L->mu);
-    // the lane's previous announced batch has been ingested out of the staging buffer (queued, at least: ev_ingest orders the rest)
+    // the lane's previous announced batch has taken its pages (its page sets have changed places): the alternate set is free again —
+    // it was the lane's current set two batches ago, and every batch ends with focr_sync
     L->cv.wait(lk, [&] { return L->pf_ptr == nullptr; });
     if (!L->copy_stream) {
         FOCR_HIP(c, hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
         FOCR_HIP(c, hipEventCreateWithFlags(&L->ev_prefetch, hipEventDisableTiming));
-        FOCR_HIP(c, hipEventCreateWithFlags(&L->ev_ingest, hipEventDisableTiming));
     }
     if (L->pf_stage_bytes < bytes) {
-        if (L->pf_ingest_recorded) FOCR_HIP(c, hipEventSynchronize(L->ev_ingest));  // nobody reads the old buffer any more
+        FOCR_HIP(c, hipStreamSynchronize(L->copy_stream));  // the previous announcement's ingest has read the old buffer
         if (L->pf_stage) (void)hipFree(L->pf_stage);
         L->pf_stage = nullptr;
         L->pf_stage_bytes = 0;
         if (hipMalloc(&L->pf_stage, bytes) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "focr_pipe_prefetch: hipMalloc failed");
         L->pf_stage_bytes = bytes;
     }
-    if (L->pf_ingest_recorded) FOCR_HIP(c, hipStreamWaitEvent(L->copy_stream, L->ev_ingest, 0));  // the previous batch's ingest has read the buffer
+    // copy, then ingest, in stream order on the lane's copy stream (the previous announcement's ingest, which read the staging buffer,
+    // is ahead of this copy on the same stream)
     FOCR_HIP(c, hipMemcpyAsync(L->pf_stage, pages, bytes, hipMemcpyHostToDevice, L->copy_stream));
+    if (int rc = pages_alt_ingest(c, L->pf_stage, n_pages, r_w, r_h, invert, L->copy_stream)) return rc;
     FOCR_HIP(c, hipEventRecord(L->ev_prefetch, L->copy_stream));
     L->pf_ptr = pages;
-    L->pf_bytes = bytes;
+    L->pf_n = n_pages;
+    L->pf_w = r_w;
+    L->pf_h = r_h;
+    L->pf_invert = invert;
     p->announced++;
     return FOCR_OK;
 }

@@ -346,14 +346,14 @@ class Pipeline:
             lane.n_pages, lane.r_w, lane.r_h = n, r_w, r_h
         return t.value
 
-    def prefetch(self, luma):
+    def prefetch(self, luma, invert=True):
         """focr_pipe_prefetch: announce the host pages (n, r_h, r_w) uint8 of the batch that will be submitted after everything
-        announced or submitted so far, and start their copy to the device now (page-locked memory: PinnedPages).  The matching
-        submit must bring the same array."""
+        announced or submitted so far, and start their copy to the device and their ingest now (page-locked memory: PinnedPages).
+        The matching submit must bring the same array (and the same `invert`, or the lane uploads the batch itself)."""
         if luma.dtype != np.uint8 or not luma.flags["C_CONTIGUOUS"] or luma.ndim != 3:
             raise ValueError("prefetch: a C-contiguous (n, r_h, r_w) uint8 array")
         n, r_h, r_w = luma.shape
-        rc = self._lib.focr_pipe_prefetch(self._h, _ptr(luma), n, r_w, r_h)
+        rc = self._lib.focr_pipe_prefetch(self._h, _ptr(luma), n, r_w, r_h, int(bool(invert)))
         if rc != 0:
             raise FocrError(f"[{rc}] {self._lib.focr_last_error_global().decode()}")
         self._announced = getattr(self, "_announced", [])

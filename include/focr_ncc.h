@@ -300,15 +300,17 @@ int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, 
                      float anchor_threshold, int32_t overlap, void *chars_out, size_t chars_out_bytes,
                      uint64_t *ticket);
 /* Announce the host pages of a batch that will be submitted AFTER every batch announced or submitted so far, and start
- * their copy to the device now: one DMA on a copy stream of the lane the batch will run on, into a staging buffer of that
- * lane's own — under the scans of the batches in flight, instead of at the head of the batch's own chain of kernels (a lane's
- * chain is what decides whether the scans of consecutive batches follow each other without a gap: DESIGN.md section 5).
- * The matching focr_pipe_submit must bring the same pointer and geometry; announced batches must be submitted in the order
- * they were announced (FOCR_ERR_STATE otherwise).  At most one announcement per lane: with n contexts, announce batch
- * b + n right after submitting batch b.  Page-locked memory (focr_host_alloc) makes the copy asynchronous.  The pages must
- * stay valid and unchanged until that batch's focr_pipe_wait returns.  Optional: a batch that was not announced is
- * uploaded by its lane as before (src/ncc.rs:575, 880-892: the reference decodes and converts inside the page loop). */
-int focr_pipe_prefetch(focr_pipe_t *pipe, const void *pages, size_t n_pages, size_t r_w, size_t r_h);
+ * their way to the device now: one DMA into a staging buffer of the lane the batch will run on, then the ingest (inversion,
+ * pitched copies) into that lane's ALTERNATE page set, both on a copy stream of the lane — under the scans of the batches in
+ * flight, instead of at the head of the batch's own chain of kernels (a lane's chain is what decides whether the scans of
+ * consecutive batches follow each other without a gap: DESIGN.md section 5).  When the batch starts, the lane's two page
+ * sets change places.  The matching focr_pipe_submit must bring the same pointer (FOCR_ERR_STATE otherwise: announced
+ * batches must be submitted in the order they were announced); with another geometry or `invert` the announcement is void
+ * and the lane uploads the batch itself.  At most one announcement per lane: with n contexts, announce batch b + n right
+ * after submitting batch b.  Page-locked memory (focr_host_alloc) makes the copy asynchronous.  The pages must stay valid
+ * and unchanged until that batch's focr_pipe_wait returns.  Optional: a batch that was not announced is uploaded by its
+ * lane as before (src/ncc.rs:575, 880-892: the reference decodes and converts inside the page loop). */
+int focr_pipe_prefetch(focr_pipe_t *pipe, const void *pages, size_t n_pages, size_t r_w, size_t r_h, int invert);
 /* Results on the host without touching the context from the consumer's thread: with fetch on, every lane copies its
  * batch's per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory
  * of its own before the batch completes; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out

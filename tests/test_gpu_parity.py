@@ -791,9 +791,9 @@ def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
 
 
 def test_pipeline_prefetch_matches_oracle(bank_x2):
-    """Round 4: batches announced ahead with focr_pipe_prefetch (their DMA runs on a copy stream while the lane still works on its
-    previous batch) — same lists as the oracle, announcements must be submitted in order, and a batch that was not announced is
-    still uploaded by its lane."""
+    """Round 4: batches announced ahead with focr_pipe_prefetch (their DMA and ingest run on a copy stream, into the lane's alternate
+    page set, while the lane still works on its previous batch) — same lists as the oracle, announcements must be submitted in order,
+    a batch that was not announced (or announced with another inversion) is still uploaded by its lane."""
     from font_ocr_amd.searcher import FocrError, PinnedPages, Pipeline
 
     n_batches, n_lanes = 8, 3
@@ -844,6 +844,22 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
         sc = pipe.wait(t)
         offsets, m = sc.matches()
         _assert_same(_csr_to_lists(offsets, m, 3, len(bank_x2)), _oracle_lists(big.array, bank_x2, 0.8, 1024), "larger announced batch")
+        pipe.release(t)
+        pipe.prefetch(pins[2].array, invert=False)  # announced with the other inversion: the announcement is void, the lane uploads the batch itself
+        t = pipe.submit(pins[2].array, 0.8)
+        sc = pipe.wait(t)
+        offsets, m = sc.matches()
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[2], "batch announced with another inversion")
+        pipe.release(t)
+        for b in (3, 4, 5, 6):  # the page sets change places batch after batch on every lane: announced batches only
+            pipe.prefetch(pins[b].array)
+            t = pipe.submit(pins[b].array, 0.8)
+            sc = pipe.wait(t)
+            offsets, m = sc.matches()
+            _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"announced batch {b} after the void one")
+            pipe.release(t)
+        t = pipe.submit(None, 0.8)  # rescan of the lane's resident pages: they are the set that was swapped in (batch 4's lane: ticket order)
+        sc = pipe.wait(t)
         pipe.release(t)
         pipe.prefetch(pins[1].array)  # an announcement that is never submitted: destroying the pipe must cope
     finally:
