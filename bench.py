@@ -689,7 +689,7 @@ def main():
 
         pipe_steps(2 * n_ctx)
         fence()
-        n_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 120))  # 0.2 s: fill + drain of the pipeline are 2-3 % of it
+        n_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 240))  # 0.4 s: fill + drain of the pipeline are 1-2 % of it
         t1 = time.perf_counter()
         pipe_steps(n_steps)
         fence()
