@@ -525,13 +525,15 @@ def main():
         main_dbg[0] += time.perf_counter() - t_w
         stamp("main", f"wait ticket {t}", t_w, time.perf_counter())
         t_r = time.perf_counter()
-        if timed:
-            for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
-                k = kern.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
-                k["ms"] += li["ms"]
-                k["n"] += 1
-            for k_, v in c_.timings().items():
-                phase[k_] = phase.get(k_, 0.0) + v
+        # the same calls in the untimed steps as in the timed ones (their results kept only from the latter): on a fresh box the
+        # first call of a library path pages its code in from the image — milliseconds, and a 20-step region is 35 of them
+        kern_, phase_ = (kern, phase) if timed else ({}, {})
+        for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
+            k = kern_.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
+            k["ms"] += li["ms"]
+            k["n"] += 1
+        for k_, v in c_.timings().items():
+            phase_[k_] = phase_.get(k_, 0.0) + v
         if use_dist:  # the lane already copied the characters into its output slot: free it for its next batch
             slot = slot_of.pop(t)
             nbytes = c_.total_chars() * HIT_DTYPE.itemsize
@@ -595,6 +597,12 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
+    if gc_mode == "freeze":
+        # HERE, not between the settling steps and the timed region: a full collection of this heap idles the GPU for 35-50 ms,
+        # its clocks fall back, and a short timed region right behind it runs its first scans 8 % slower (20 steps: 29.9 against
+        # 32.2 Gpx/s at 300 steps, the same box; tools/r4_k20.sh) — the steps below bring the clocks back before the clock starts
+        gc.collect()
+        gc.freeze()
     t_settle = time.perf_counter()
     go = args.settle_s > 0
     while go:
@@ -606,9 +614,6 @@ def main():
             flag = torch.tensor([1 if go else 0], device=coll_dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go = bool(flag.item())
-    if gc_mode == "freeze":
-        gc.collect()
-        gc.freeze()
     timed = True
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -687,9 +692,9 @@ def main():
                 pipe.wait(t)
                 pipe.release(t)
 
-        pipe_steps(2 * n_ctx)
+        pipe_steps(120)  # 0.2 s: page-locking the source buffers left the GPU idle, and its clocks take that long to come back
         fence()
-        n_steps = args.steps if args.with_upload else max(2 * n_ctx, min(args.steps, 240))  # 0.4 s: fill + drain of the pipeline are 1-2 % of it
+        n_steps = 240  # 0.4 s whatever --steps says: fill + drain of the pipeline are 1-2 % of it
         t1 = time.perf_counter()
         pipe_steps(n_steps)
         fence()
