@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--with-upload", action="store_true", help="also time steps that start from PAGEABLE host pages, upload and scan back to back (e2e_value_incl_h2d)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the short untimed leg that measures the pipelined PCIe-inclusive rate (e2e_value_incl_h2d_pipelined)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher / timing-protocol self-test on the gloo backend with a stub step: no GPU, not a measurement")
-    ap.add_argument("--settle-s", type=float, default=0.4, help="untimed extra warm-up (seconds of steps) before the timed region")
+    ap.add_argument("--settle-s", type=float, default=0.8, help="untimed extra warm-up (seconds of steps) before the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     ap.add_argument("--scan-cus", type=int, default=-1,
                     help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
@@ -590,7 +590,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Untimed: the W warm-up steps, then — still untimed — more of the same steps until ~0.4 s of device work has gone by:
+    # Untimed: the W warm-up steps, then — still untimed — more of the same steps until ~0.8 s of device work has gone by:
     # the first scan of every context reads its result sizes synchronously (later ones run on those sizes), buffers grow to
     # their steady size, and the GPU's clocks take a few hundred ms under load to settle; a 20-step timed region (~50 ms)
     # measured right after 5 steps was 8 % below a 100-step one.

@@ -7,3 +7,4 @@ for k in kernel_trace memory_copy_trace; do f=$(find $out/tmp_e2e -name "*${k}.c
 python3 tools/e2e_timeline.py $out/e2e_kernel_trace.csv $out/e2e_memory_copy_trace.csv > $out/e2e_timeline.log 2>&1; rm -f $out/e2e_kernel_trace.csv $out/e2e_memory_copy_trace.csv; say "e2e timeline done"
 rm -f $out/e2e_legs.jsonl; for rep in 1 2; do for v in "" "--no-prefetch" "--resident" "--in-flight 4" "--in-flight 4 --resident"; do python3 tools/e2e_leg.py --steps 240 $v >> $out/e2e_legs.jsonl 2>/dev/null; done; done; say "e2e legs:"; cat $out/e2e_legs.jsonl
 head -30 $out/e2e_timeline.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err; say "the driver's own command done: $(cut -c60-130 $out/bench_driver_cmd.json)"
