@@ -509,7 +509,8 @@ namespace focr {
 // is free whenever this is called: it was current two batches ago, and every batch of a lane ends with focr_sync.
 int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s) {
     if (!c || !d_luma || !n_pages || !r_w || !r_h || r_w > 65535 || r_h > 65535 || n_pages > 65535)
-        return fail(c, FOCR_ERR_INVALID, "pages_alt_ingest: bad arguments");
+        return fail(nullptr, FOCR_ERR_INVALID, "pages_alt_ingest: bad arguments");
+    // (errors go to the process-wide message only: the context's own belongs to the lane's thread, which may be running a batch)
     focr_ctx::PageSet &a = c->alt;
     if (!a.u8 || a.r_w != r_w || a.r_h != r_h || a.capacity < n_pages) {
         free_dev(a.u8);  // (hipFree waits for the device: a change of geometry, not the steady state)
@@ -520,22 +521,22 @@ int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w
         if (hipMalloc(&a.u8, bytes) != hipSuccess || hipMalloc(&a.i8, bytes) != hipSuccess) {
             free_dev(a.u8);
             free_dev(a.i8);
-            return fail(c, FOCR_ERR_NOMEM, "pages_alt_ingest: hipMalloc failed");
+            return fail(nullptr, FOCR_ERR_NOMEM, "pages_alt_ingest: hipMalloc failed");
         }
         a.capacity = n_pages;
         a.r_w = r_w;
         a.r_h = r_h;
         a.pitch = pitch;
         a.rows_alloc = rows_alloc;
-        FOCR_HIP(c, hipMemsetAsync(a.u8, 0, bytes, s));
-        FOCR_HIP(c, hipMemsetAsync(a.i8, 0x80, bytes, s));  // paper (0) as int8
+        FOCR_HIP((focr_ctx *)nullptr, hipMemsetAsync(a.u8, 0, bytes, s));
+        FOCR_HIP((focr_ctx *)nullptr, hipMemsetAsync(a.i8, 0x80, bytes, s));  // paper (0) as int8
     }
     const size_t n_rows = n_pages * r_h;
     const unsigned blocks = (unsigned)std::min<size_t>(n_rows, (size_t)1 << 20);
     const int dwords = r_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_luma) & 3) == 0;
     hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(64), 0, s, (const uint8_t *)d_luma, a.u8, a.i8, (uint32_t)r_w, (uint32_t)r_h, a.pitch, a.rows_alloc, (size_t)0,
                        n_rows, invert, dwords);
-    FOCR_HIP(c, hipGetLastError());
+    FOCR_HIP((focr_ctx *)nullptr, hipGetLastError());
     return FOCR_OK;
 }
 

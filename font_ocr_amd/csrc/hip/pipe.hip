@@ -333,28 +333,28 @@ int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t
     PipeLane *L = p->lanes[(p->next_ticket + p->announced - 1) % p->lanes.size()];
     focr_ctx *c = L->ctx;
     const size_t bytes = n_pages * r_w * r_h;
-    FOCR_HIP(c, hipSetDevice(c->device));
+    FOCR_HIP((focr_ctx *)nullptr, hipSetDevice(c->device));
     std::unique_lock<std::mutex> lk(L->mu);
     // the lane's previous announced batch has taken its pages (its page sets have changed places): the alternate set is free again —
     // it was the lane's current set two batches ago, and every batch ends with focr_sync
     L->cv.wait(lk, [&] { return L->pf_ptr == nullptr; });
     if (!L->copy_stream) {
-        FOCR_HIP(c, hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
-        FOCR_HIP(c, hipEventCreateWithFlags(&L->ev_prefetch, hipEventDisableTiming));
+        FOCR_HIP((focr_ctx *)nullptr, hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
+        FOCR_HIP((focr_ctx *)nullptr, hipEventCreateWithFlags(&L->ev_prefetch, hipEventDisableTiming));
     }
     if (L->pf_stage_bytes < bytes) {
-        FOCR_HIP(c, hipStreamSynchronize(L->copy_stream));  // the previous announcement's ingest has read the old buffer
+        FOCR_HIP((focr_ctx *)nullptr, hipStreamSynchronize(L->copy_stream));  // the previous announcement's ingest has read the old buffer
         if (L->pf_stage) (void)hipFree(L->pf_stage);
         L->pf_stage = nullptr;
         L->pf_stage_bytes = 0;
-        if (hipMalloc(&L->pf_stage, bytes) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "focr_pipe_prefetch: hipMalloc failed");
+        if (hipMalloc(&L->pf_stage, bytes) != hipSuccess) return fail(nullptr, FOCR_ERR_NOMEM, "focr_pipe_prefetch: hipMalloc failed");
         L->pf_stage_bytes = bytes;
     }
     // copy, then ingest, in stream order on the lane's copy stream (the previous announcement's ingest, which read the staging buffer,
     // is ahead of this copy on the same stream)
-    FOCR_HIP(c, hipMemcpyAsync(L->pf_stage, pages, bytes, hipMemcpyHostToDevice, L->copy_stream));
+    FOCR_HIP((focr_ctx *)nullptr, hipMemcpyAsync(L->pf_stage, pages, bytes, hipMemcpyHostToDevice, L->copy_stream));
     if (int rc = pages_alt_ingest(c, L->pf_stage, n_pages, r_w, r_h, invert, L->copy_stream)) return rc;
-    FOCR_HIP(c, hipEventRecord(L->ev_prefetch, L->copy_stream));
+    FOCR_HIP((focr_ctx *)nullptr, hipEventRecord(L->ev_prefetch, L->copy_stream));
     L->pf_ptr = pages;
     L->pf_n = n_pages;
     L->pf_w = r_w;
