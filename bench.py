@@ -575,6 +575,8 @@ def main():
 
     def fence(barrier=True):
         nonlocal n_chars
+        if not os.environ.get("FOCR_BENCH_NO_EOS"):
+            pipe.end_of_stream()  # nothing follows the batches in flight: the newest one's tail may take the whole chip (focr_pipe_end_of_stream)
         while jobs:
             retire()
         if use_dist:
@@ -687,6 +689,7 @@ def main():
                 tickets.append(pipe.submit(pins[k % n_ctx].array, args.threshold, 1024, mode, True, 0.95, 5))
                 if k + ahead < n:
                     pipe.prefetch(pins[(k + ahead) % n_ctx].array)
+            pipe.end_of_stream()
             while tickets:
                 t = tickets.popleft()
                 pipe.wait(t)

@@ -129,6 +129,7 @@ HIP_SYMBOLS = {
                                    C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_uint64)]),
     "focr_pipe_prefetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "focr_pipe_end_of_stream": (C.c_int, [C.c_void_p]),
     "focr_pipe_set_fetch": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_pipe_host_results": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "focr_get_lines_into": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -142,6 +143,7 @@ HIP_SYMBOLS = {
     "focr_fleet_device_of": (C.c_int, [C.c_void_p, C.c_uint64]),
     "focr_fleet_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "focr_fleet_set_fetch": (C.c_int, [C.c_void_p, C.c_int]),
+    "focr_fleet_end_of_stream": (C.c_int, [C.c_void_p]),
     "focr_fleet_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_uint32,
                                     C.c_int, C.c_int, C.c_float, C.c_int32, C.POINTER(C.c_uint64)]),
     "focr_fleet_wait": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),

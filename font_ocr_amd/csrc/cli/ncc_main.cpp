@@ -611,6 +611,7 @@ int main(int argc, char **argv) {
                               &tickets[b]) != FOCR_OK)
             fatal(std::string("focr_fleet_submit: ") + focr_last_error_global());
     }
+    (void)focr_fleet_end_of_stream(fleet);  // nothing follows: the last batches' tails need not leave room for a next scan
     while (next_retire < n_batches) retire(next_retire++);
     stop_pool();
     if (args.verbose) {

@@ -97,6 +97,13 @@ int focr_fleet_bank_upload(focr_fleet_t *f, const focr_template_t *templates, si
     return FOCR_OK;
 }
 
+int focr_fleet_end_of_stream(focr_fleet_t *f) {
+    if (!f) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_end_of_stream: null fleet");
+    std::lock_guard<std::mutex> lk(f->mu);  // not between a submit's ticket and its pipe
+    for (focr_pipe_t *p : f->pipes) focr_pipe_end_of_stream(p);
+    return FOCR_OK;
+}
+
 int focr_fleet_set_fetch(focr_fleet_t *f, int on) {
     if (!f) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_set_fetch: null fleet");
     for (focr_pipe_t *p : f->pipes) focr_pipe_set_fetch(p, on);

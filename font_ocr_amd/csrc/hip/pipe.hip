@@ -299,6 +299,8 @@ int focr_pipe_submit(focr_pipe_t *p, const void *pages, int pages_on_device, siz
             p->announced--;
         }
         t = p->next_ticket++;
+        p->gate.newest.store(t, std::memory_order_relaxed);
+        p->gate.closing.store(false, std::memory_order_relaxed);
     }
     PipeLane *L = p->lanes[(t - 1) % p->lanes.size()];
     {
@@ -361,6 +363,13 @@ int focr_pipe_prefetch(focr_pipe_t *p, const void *pages, size_t n_pages, size_t
     L->pf_h = r_h;
     L->pf_invert = invert;
     p->announced++;
+    return FOCR_OK;
+}
+
+int focr_pipe_end_of_stream(focr_pipe_t *p) {
+    if (!p) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_end_of_stream: null pipe");
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->gate.closing.store(true, std::memory_order_relaxed);  // until the next submit
     return FOCR_OK;
 }
 

@@ -359,6 +359,10 @@ class Pipeline:
         self._announced = getattr(self, "_announced", [])
         self._announced.append(luma)  # kept alive until its submit takes over
 
+    def end_of_stream(self):
+        """focr_pipe_end_of_stream: nothing follows the newest batch for now (until the next submit): its tail may take the whole GPU."""
+        self._lib.focr_pipe_end_of_stream(self._h)
+
     def wait(self, ticket):
         """Blocks until the batch is done; returns the Scanner whose getters (matches, lines, counts...) see it."""
         h = C.c_void_p()

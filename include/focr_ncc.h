@@ -311,6 +311,11 @@ int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, 
  * and unchanged until that batch's focr_pipe_wait returns.  Optional: a batch that was not announced is uploaded by its
  * lane as before (src/ncc.rs:575, 880-892: the reference decodes and converts inside the page loop). */
 int focr_pipe_prefetch(focr_pipe_t *pipe, const void *pages, size_t n_pages, size_t r_w, size_t r_h, int invert);
+/* Optional hint: nothing will be submitted behind the newest batch for now (the end of the host's input; the next
+ * focr_pipe_submit takes the hint back).  The tail kernels of that last batch then take the whole GPU instead of the share the
+ * persistent scan kernel of a following batch would leave them — the stream's last results arrive about a millisecond earlier.
+ * Call it right after the last submit; results are the same either way. */
+int focr_pipe_end_of_stream(focr_pipe_t *pipe);
 /* Results on the host without touching the context from the consumer's thread: with fetch on, every lane copies its
  * batch's per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory
  * of its own before the batch completes; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out
@@ -352,6 +357,7 @@ int focr_fleet_device_of(const focr_fleet_t *fleet, uint64_t ticket);  /* HIP de
 int focr_fleet_bank_upload(focr_fleet_t *fleet, const focr_template_t *templates, size_t n_templates,
                            const uint8_t *needles, size_t needles_len);
 int focr_fleet_set_fetch(focr_fleet_t *fleet, int on);
+int focr_fleet_end_of_stream(focr_fleet_t *fleet);  /* focr_pipe_end_of_stream on every device's executor */
 int focr_fleet_submit(focr_fleet_t *fleet, const void *pages, int pages_on_device, size_t n_pages, size_t r_w, size_t r_h,
                       int invert, float threshold, uint32_t cap, int mode, int process_hits, float anchor_threshold,
                       int32_t overlap, uint64_t *ticket);

@@ -134,6 +134,8 @@ def test_fuzz_for_a_time_budget():
                             _assert_same(_csr_to_lists(offsets, m, n_pages, len(bank)), wants[b - n_lanes], f"{what} pipeline batch {b - n_lanes}")
                             pipe.release(tickets[b - n_lanes])
                             stat["pipeline_batches"] += 1
+                        if b == n_batches:
+                            pipe.end_of_stream()
                         if b < n_batches:
                             tickets.append(pipe.submit(pins[b].array, thr, cap))
                             if b + n_lanes < n_batches:

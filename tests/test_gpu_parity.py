@@ -824,6 +824,7 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
             tickets.append(pipe.submit(pins[b].array, 0.8))
             if b + n_lanes < n_batches:
                 pipe.prefetch(pins[b + n_lanes].array)
+        pipe.end_of_stream()  # nothing follows for now: the newest batch's tail may take the whole chip; same lists (the next submit takes the hint back)
         for b in range(n_batches - n_lanes, n_batches):
             sc = pipe.wait(tickets[b])
             offsets, m = sc.matches()

@@ -51,6 +51,7 @@ def run(n, resident):
         tickets.append(pipe.submit(None if resident else pins[k % n_pins].array, 0.8, 1024, SCAN_MFMA, True, 0.95, 5))
         if ahead and k + ahead < n:
             pipe.prefetch(pins[(k + ahead) % n_pins].array)
+    pipe.end_of_stream()
     while tickets:
         t = tickets.popleft()
         pipe.wait(t)

@@ -1,6 +1,6 @@
 # 20-step (the driver's K) and 300-step values: base library (tools/bin/libfocr_hip_base.so) against this tree, alternating
 set -o pipefail
-for rep in 1 2 3; do
+for rep in 1 2 3 4 5; do
   for which in base new; do
     for k in 20 300; do
       if [ $which = base ]; then export FOCR_HIP_LIB=$PWD/tools/bin/libfocr_hip_base.so; else unset FOCR_HIP_LIB; fi
