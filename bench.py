@@ -292,9 +292,14 @@ def main():
                     help="CUs the persistent scan kernel occupies; 0 = all, -1 = auto: all with one batch in flight, else 7/8 "
                          "of them (the rest is left to the other contexts' small kernels; flat optimum 192..224 of 256: DESIGN.md section 5)")
     ap.add_argument("--in-flight", type=int, default=3,
-                    help="batches in flight per GPU: that many contexts (each with its own resident batch, HIP stream and host "
-                         "thread) take the steps round-robin, so one batch's statistics / sort / verify / ordering kernels "
-                         "overlap another's MFMA scan; 1 = strictly one batch at a time")
+                    help="lanes of the executor (focr_pipe_*): that many HIP streams run batches side by side, so one batch's statistics / "
+                         "verify / sort / ordering kernels overlap another's MFMA scan; 1 = strictly one batch at a time on the device")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="contexts per lane: a lane's next batch is queued on the device behind the one that runs (each context holds its own "
+                         "resident batch); lanes x depth batches are outstanding at the host")
+    ap.add_argument("--inject-stall-ms", type=float, default=0.0,
+                    help="self-test of the executor's tolerance: the submitting thread sleeps this long every --inject-stall-every timed steps")
+    ap.add_argument("--inject-stall-every", type=int, default=10)
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -357,13 +362,15 @@ def main():
         bank_file = "bank_dejavu13_ascii95_x2y2.bin"
     bank = Bank.load(os.path.join(ROOT, "tests", "golden", bank_file))
     P = args.pages_per_gpu
-    n_ctx = max(1, args.in_flight)
+    n_lanes = max(1, args.in_flight)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_ctx == 1 else n_cus - n_cus // 8)
-    # The executor: n_ctx contexts with a native worker thread each (focr_pipe_*, include/focr_ncc.h)
+    scan_cus = args.scan_cus if args.scan_cus >= 0 else (0 if n_lanes == 1 else n_cus - n_cus // 8)
+    # The executor (focr_pipe_*, include/focr_ncc.h): n_lanes streams, --depth contexts each; every batch is queued on the device
+    # the moment it is submitted, so n_ctx = lanes x depth batches are outstanding at the host
     from font_ocr_amd.searcher import Pipeline
 
-    pipe = Pipeline(local_rank, n_ctx)
+    pipe = Pipeline(local_rank, n_lanes, max(1, args.depth))
+    n_ctx = len(pipe.scanners)
     for c_ in pipe.scanners:
         if args.no_column_drop:
             c_.set_column_drop(False)
@@ -515,6 +522,7 @@ def main():
     phase = {}
     n_chars = 0
     timed = False
+    ticket_log = []  # focr_pipe_ticket_times of every batch retired inside the timed region
 
     def retire():
         """Consume the oldest step in flight: its results stay on the device; with several ranks they are gathered."""
@@ -528,6 +536,9 @@ def main():
         # the same calls in the untimed steps as in the timed ones (their results kept only from the latter): on a fresh box the
         # first call of a library path pages its code in from the image — milliseconds, and a 20-step region is 35 of them
         kern_, phase_ = (kern, phase) if timed else ({}, {})
+        tt = pipe.ticket_times(t)
+        if timed:
+            ticket_log.append(tt)
         for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
             k = kern_.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))
             k["ms"] += li["ms"]
@@ -544,16 +555,30 @@ def main():
             n_chars = c_.total_chars() or n_chars
             pipe.release(t)
 
-    def step(k):
+    def step(k, last=False):
+        """last: nothing is submitted behind this step until the pipeline has drained (the end of a timed / settling sequence): said
+        BEFORE the submit (focr_pipe_announce_last) — batches are queued on the device the moment they are submitted."""
         if shard is not None:  # one step = the rank's whole shard, batch by batch, ingested device -> device from the resident tensor
-            for b0, nb in shard_batches:
+            for i, (b0, nb) in enumerate(shard_batches):
+                if last and i + 1 == len(shard_batches) and not os.environ.get("FOCR_BENCH_NO_EOS"):
+                    pipe.announce_last()
                 submit_one(device_ptr=shard[b0].data_ptr(), shape=(nb, R_H, R_W))
         else:
+            if last and not os.environ.get("FOCR_BENCH_NO_EOS"):
+                pipe.announce_last()
             submit_one()
 
+    host_gap = {"last": None, "max": 0.0, "waited": 0.0}  # the submitting thread's own time between two submits (waiting for a batch excluded)
+
     def submit_one(device_ptr=None, shape=None):
-        if len(jobs) == n_ctx:  # the lane this batch maps to still holds the batch submitted n_ctx submissions ago
+        if len(jobs) == n_ctx:  # the context this batch maps to still holds the batch submitted n_ctx submissions ago
+            w0 = main_dbg[0]
             retire()
+            host_gap["waited"] += main_dbg[0] - w0
+        now_ = time.perf_counter()
+        if timed and host_gap["last"] is not None:
+            host_gap["max"] = max(host_gap["max"], now_ - host_gap["last"] - host_gap["waited"])
+        host_gap["last"], host_gap["waited"] = now_, 0.0
         if use_dist:
             slot = next_slot[0] % len(out_bufs)
             next_slot[0] += 1
@@ -575,8 +600,6 @@ def main():
 
     def fence(barrier=True):
         nonlocal n_chars
-        if not os.environ.get("FOCR_BENCH_NO_EOS"):
-            pipe.end_of_stream()  # nothing follows the batches in flight: the newest one's tail may take the whole chip (focr_pipe_end_of_stream)
         while jobs:
             retire()
         if use_dist:
@@ -597,7 +620,7 @@ def main():
     # their steady size, and the GPU's clocks take a few hundred ms under load to settle; a 20-step timed region (~50 ms)
     # measured right after 5 steps was 8 % below a 100-step one.
     for k in range(args.warmup):
-        step(k)
+        step(k, last=k + 1 == args.warmup)
     fence()
     if gc_mode == "freeze":
         # HERE, not between the settling steps and the timed region: a full collection of this heap idles the GPU for 35-50 ms,
@@ -609,7 +632,7 @@ def main():
     go = args.settle_s > 0
     while go:
         for k in range(2 * n_ctx):
-            step(k)
+            step(k, last=k + 1 == 2 * n_ctx)
         fence()
         go = time.perf_counter() - t_settle < args.settle_s
         if use_dist and world > 1:  # every rank must run the same number of rounds: each one ends in collectives (fence)
@@ -617,11 +640,16 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             go = bool(flag.item())
     timed = True
+    host_gap["last"] = None
     t0 = time.perf_counter()
+    n_stalls = 0
     for k in range(args.steps):
         if k == args.steps // 2:
             injected_failure(rank, "step")
-        step(k)
+        if args.inject_stall_ms > 0 and k and k % max(1, args.inject_stall_every) == 0:
+            time.sleep(args.inject_stall_ms / 1e3)  # a host that is late with its next batch: the device works on what is queued
+            n_stalls += 1
+        step(k, last=k + 1 == args.steps)
     fence(barrier=False)
     dt_own = time.perf_counter() - t0  # this rank's own work done (per_rank_value); the job's time includes the barrier
     fence()
@@ -686,10 +714,11 @@ def main():
                     t = tickets.popleft()
                     pipe.wait(t)
                     pipe.release(t)
+                if k + 1 == n:
+                    pipe.announce_last()
                 tickets.append(pipe.submit(pins[k % n_ctx].array, args.threshold, 1024, mode, True, 0.95, 5))
                 if k + ahead < n:
                     pipe.prefetch(pins[(k + ahead) % n_ctx].array)
-            pipe.end_of_stream()
             while tickets:
                 t = tickets.popleft()
                 pipe.wait(t)
@@ -717,7 +746,7 @@ def main():
     # the dominant kernel alone on the chip (no other batch in flight, all CUs): a short extra leg outside the timed
     # region, reported beside the in-flight figure so that both ways of reading "kernel duration" are on the table
     iso = {}
-    if rank == 0 and n_ctx > 1 and not leg_errors:  # (a failed PCIe leg leaves the lanes in an unknown state)
+    if rank == 0 and n_lanes > 1 and not leg_errors:  # (a failed PCIe leg leaves the lanes in an unknown state)
         try:
             sc.set_scan_cus(0)
             for i in range(14):  # 4 to settle (the leg starts from an idle GPU), 10 measured
@@ -776,7 +805,9 @@ def main():
                               "(1520 templates, 16 sub-pixel shifts), threshold 0.8, cap 1024, + process_hits(0.95, 5)"),
             "pages_per_batch": P,
             "resident_pages_per_gpu": P * n_ctx,
-            "batches_in_flight": n_ctx,
+            "batches_in_flight": n_lanes,
+            "contexts_per_lane": n_ctx // n_lanes,
+            "batches_outstanding_at_host": n_ctx,
             "scan_cus": scan_cus or n_cus,
             "templates": len(bank),
             "scan_mode": args.mode,
@@ -798,6 +829,38 @@ def main():
                              "note": "every step rescans the same resident batches, so the result-size estimates run at their smallest margin "
                                      "with nothing redone; different batches per step: --config c4"}
     out["host_gc"] = host_gc
+    if ticket_log:
+        # Where the timed region's time went, ticket by ticket (focr_pipe_ticket_times: host stamps of the executor + the device-side
+        # interval between consecutive batches' last kernels) — so that ONE late submit or one slow batch can be told from uniform slowness
+        def pct(v, q):
+            v = sorted(v)
+            return v[min(len(v) - 1, int(q * len(v)))] if v else None
+
+        done = [t_["done_us"] for t_ in ticket_log]
+        sub = [t_["submit_us"] for t_ in ticket_log]
+        host_iv = [(b_ - a_) / 1e3 for a_, b_ in zip(done, done[1:])]
+        dev_iv = [t_["device_gap_ms"] for t_ in ticket_log[1:] if t_["device_gap_ms"] >= 0]
+        sub_iv = [(b_ - a_) / 1e3 for a_, b_ in zip(sub, sub[1:])]
+        lead = [(t_["done_us"] - t_["enqueue_end_us"]) / 1e3 for t_ in ticket_log]  # how long a batch sat fully queued before its results were seen
+        out["step_stats"] = {
+            "batches": len(ticket_log),
+            "first_completion_ms": round((done[0] - sub[0]) / 1e3, 3),
+            "completion_interval_ms_p50": round(pct(host_iv, 0.5), 4) if host_iv else None,
+            "completion_interval_ms_max": round(max(host_iv), 4) if host_iv else None,
+            "device_interval_ms_p50": round(pct(dev_iv, 0.5), 4) if dev_iv else None,
+            "device_interval_ms_max": round(max(dev_iv), 4) if dev_iv else None,
+            "longest_submit_gap_ms": round(max(sub_iv), 4) if sub_iv else None,
+            "longest_host_gap_ms": round(host_gap["max"] * 1e3, 4),
+            "executor_queueing_ms_p50": round(pct([(t_["enqueue_end_us"] - t_["enqueue_begin_us"]) / 1e3 for t_ in ticket_log], 0.5), 4),
+            "executor_pickup_ms_max": round(max((t_["enqueue_begin_us"] - t_["submit_us"]) / 1e3 for t_ in ticket_log), 4),
+            "queued_ahead_ms_min": round(min(lead), 3),
+            "injected_host_stalls": n_stalls,
+            "injected_stall_ms": args.inject_stall_ms,
+            "note": "per batch retired in the timed region: host-side completion intervals (when the retiring thread saw each batch done), device-side "
+                    "intervals between consecutive batches' last kernels (HIP events), the longest pause between two submits (with / without the time the "
+                    "submitting thread waited for the oldest batch: 'longest_host_gap_ms' is the host's own lateness), the executor thread's time "
+                    "to queue one batch and its longest delay in picking one up, and the least time a batch had been fully queued before it completed",
+        }
     if per_rank is not None:
         out["per_rank_value"] = per_rank
     if args.noise:
@@ -830,7 +893,7 @@ def main():
                     "compulsory HBM traffic is 1 B/px (hbm_frac below), the path is MFMA-bound (SURVEY.md 8d)",
             "hbm_frac_compulsory": round(value * 1e6 * 1.0 / 8.0e12, 8),
         }
-        if n_ctx > 1:
+        if n_lanes > 1:
             # per-launch durations stretch when launches of several contexts share the chip; two more readings:
             step_alg = sum(v["alg"] * v["n"] for v in kern.values()) / args.steps  # algorithmic MACs per step, all scan launches
             out["roofline"]["frac_whole_step"] = round(2.0 * step_alg / (dt / args.steps) / 1e12 / PEAK_I8_MFMA_TOPS, 4)
@@ -838,7 +901,7 @@ def main():
                 iso_ms = iso[key]["ms"] / iso[key]["n"]
                 out["roofline"]["isolated_avg_kernel_ms"] = round(iso_ms, 4)
                 out["roofline"]["frac_isolated"] = round(2.0 * k["alg"] / (iso_ms / 1e3) / 1e12 / PEAK_I8_MFMA_TOPS, 4)
-            out["roofline"]["note"] += (f"; {n_ctx} batches in flight: 'achieved'/'frac' use the per-launch duration inside the timed region "
+            out["roofline"]["note"] += (f"; {n_lanes} batches in flight: 'achieved'/'frac' use the per-launch duration inside the timed region "
                                         "(launches of different contexts overlap, so it is longer than the kernel alone), "
                                         "'frac_isolated' = same kernel alone on all CUs (extra untimed leg), "
                                         "'frac_whole_step' = algorithmic ops of one step / wall time of one step")

@@ -75,6 +75,13 @@ class LaunchInfo(C.Structure):
                 ("issued_macs", C.c_uint64)]
 
 
+class TicketTimes(C.Structure):
+    """focr_ticket_times_t (include/focr_ncc.h)."""
+
+    _fields_ = [("submit_us", C.c_double), ("enqueue_begin_us", C.c_double), ("scan_queued_us", C.c_double), ("enqueue_end_us", C.c_double),
+                ("done_us", C.c_double), ("device_gap_ms", C.c_float)]
+
+
 _NCC_ARGS = [
     C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
     C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
@@ -121,7 +128,11 @@ HIP_SYMBOLS = {
     "focr_debug_prefilter": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_pipe_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "focr_pipe_create2": (C.c_int, [C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_void_p)]),
     "focr_pipe_destroy": (None, [C.c_void_p]),
+    "focr_pipe_lanes": (C.c_uint, [C.c_void_p]),
+    "focr_pipe_announce_last": (C.c_int, [C.c_void_p]),
+    "focr_pipe_ticket_times": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "focr_pipe_contexts": (C.c_uint, [C.c_void_p]),
     "focr_pipe_context": (C.c_void_p, [C.c_void_p, C.c_uint]),
     "focr_pipe_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
@@ -139,6 +150,8 @@ HIP_SYMBOLS = {
     "focr_fleet_destroy": (None, [C.c_void_p]),
     "focr_fleet_devices": (C.c_uint, [C.c_void_p]),
     "focr_fleet_lanes": (C.c_uint, [C.c_void_p]),
+    "focr_fleet_slots": (C.c_uint, [C.c_void_p]),
+    "focr_fleet_announce_last": (C.c_int, [C.c_void_p]),
     "focr_fleet_pipe": (C.c_void_p, [C.c_void_p, C.c_uint]),
     "focr_fleet_device_of": (C.c_int, [C.c_void_p, C.c_uint64]),
     "focr_fleet_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),

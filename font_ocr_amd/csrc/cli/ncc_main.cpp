@@ -314,8 +314,9 @@ int main(int argc, char **argv) {
     //   2. the same cores decode, in index order, straight into their page's slot (binary PGM: one fread), while the
     //      main thread brings the HIP runtime up and page-locks the slabs (focr_host_register);
     //   3. a decoded batch goes to the next device round-robin (every visible GPU, FOCR_CLI_DEVICES caps the count) as
-    //      ONE upload + scan + process_hits on one lane of that device's executor (focr_pipe_*: FOCR_CLI_CONTEXTS lanes
-    //      per device, default 3), so a batch's DMA and small kernels run under other batches' MFMA scans;
+    //      ONE upload + scan + process_hits in one context of that device's executor (focr_pipe_*: FOCR_CLI_CONTEXTS lanes
+    //      per device, default 3, two contexts each), queued on the device at once: a batch's DMA and small kernels run under
+    //      other batches' MFMA scans and no lane waits for this thread between two batches;
     //   4. results are retired in batch order and written in page order: the bytes on stdout are those of the
     //      reference's sorted print (src/ncc.rs:845-877) whatever the device count.
     const size_t N = args.img.size();
@@ -373,7 +374,7 @@ int main(int argc, char **argv) {
     if (const char *e = getenv("FOCR_CLI_DEVICES")) dev_cap = std::max<size_t>(1, strtoul(e, nullptr, 10));
     if (args.raw) n_lanes = 1, dev_cap = 1;
 
-    // 2. slabs: enough for every lane of every device to hold one batch plus a few being decoded ahead
+    // 2. slabs: enough for every context of every device's executor to hold one batch plus a few being decoded ahead
     const size_t slab_bytes = (max_bytes + 4095) / 4096 * 4096;
     std::mutex mu;
     std::condition_variable cv;
@@ -448,7 +449,7 @@ int main(int argc, char **argv) {
         focr_fleet_set_fetch(fleet, 1);  // every lane copies its batch's counts and lines to page-locked memory itself
     }
     {  // the remaining slabs, and page-lock all of them (a slab that cannot be locked still works, through a staged copy)
-        const size_t want = std::min(n_batches, n_dev * n_lanes + 4);
+        const size_t want = std::min<size_t>(n_batches, focr_fleet_slots(fleet) + 4);
         std::vector<uint8_t *> more;
         for (size_t k = slabs.size(); k < want; k++) {
             void *p = nullptr;
@@ -590,10 +591,11 @@ int main(int argc, char **argv) {
     }
 
     // 3 + 4. submit in batch order (device b % n_dev, lanes round-robin inside the executor), retire in batch order
-    const size_t max_inflight = n_dev * n_lanes;
+    const size_t max_inflight = focr_fleet_slots(fleet);  // devices x lanes x contexts per lane
     size_t next_retire = 0;
     for (size_t b = 0; b < n_batches; b++) {
-        while (b - next_retire >= max_inflight) retire(next_retire++);  // the lane batch b maps to still holds batch b - max_inflight
+        while (b - next_retire >= max_inflight) retire(next_retire++);  // the context batch b maps to still holds batch b - max_inflight
+        if (b + n_dev == n_batches) (void)focr_fleet_announce_last(fleet);  // the devices' last batches: their tails need not leave room for a next scan
         auto t0 = now();
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -611,7 +613,6 @@ int main(int argc, char **argv) {
                               &tickets[b]) != FOCR_OK)
             fatal(std::string("focr_fleet_submit: ") + focr_last_error_global());
     }
-    (void)focr_fleet_end_of_stream(fleet);  // nothing follows: the last batches' tails need not leave room for a next scan
     while (next_retire < n_batches) retire(next_retire++);
     stop_pool();
     if (args.verbose) {

@@ -5,8 +5,6 @@
 
 #include <cstdint>
 #include <cstdio>
-#include <atomic>
-#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -119,46 +117,17 @@ constexpr uint32_t COUNTER_WORDS = 64, QUEUE_XCDS = 8, QUEUE_STRIDE = 32, MAX_SC
 constexpr uint32_t TAIL_DONE_WORD = 56, ORDER_DONE_WORD = 57;  // d_counter words: workgroups of the verify / of unit_prefix that have finished ("last workgroup" work)
 constexpr size_t COUNTER_BYTES = (COUNTER_WORDS + (size_t)MAX_SCAN_QUEUES * QUEUE_XCDS * QUEUE_STRIDE) * sizeof(uint32_t);
 
-namespace focr {
-// Scans of one executor (pipe.hip) are queued in TICKET order.  The contexts of a device take turns with the persistent scan
-// kernel (launch_scan_mfma); left to the order in which their host threads happen to get there, a batch submitted later can
-// scan — and so finish — before an earlier one, and a host that retires batches in submission order then holds the early
-// finisher's lane idle until the straggler is done: the lanes fall into step, all statistics kernels run at once and nothing
-// scans meanwhile (seen in kernel timelines of BASELINE configs[1] after every drain of the pipeline).  A ticket passes the gate
-// when every earlier ticket has queued its scan (or ended without one).
-struct TurnGate {
-    std::mutex mu;
-    std::condition_variable cv;
-    uint64_t next = 1;  // the lowest ticket that has not passed yet
-    // the newest ticket submitted to the executor, and whether the host has said that nothing follows it for now
-    // (focr_pipe_end_of_stream; the next submit takes it back): the tail of such a batch has nobody scanning behind it and may
-    // take the whole chip (rows2_verify).  "Newest" alone does not say so: with three lanes the batch that queues its tail often IS
-    // the newest one in steady state, its successor arriving a moment later (tried: 300 steps -1.8 %).
-    std::atomic<uint64_t> newest{0};
-    std::atomic<bool> closing{false};
-    void enter(uint64_t t) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return next >= t; });
-    }
-    void leave(uint64_t t) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (next == t) next = t + 1;
-        }
-        cv.notify_all();
-    }
-    void skip(uint64_t t) {  // a batch that ends without a scan turn (error, direct mode) must not hold up the later ones
-        enter(t);
-        leave(t);
-    }
-};
-}  // namespace focr
-
 struct focr_ctx {
     int device = -1;
-    focr::TurnGate *turn_gate = nullptr;  // set by the executor that drives this context (pipe.hip), with the batch's ticket
-    uint64_t turn_ticket = 0;
     hipStream_t stream = nullptr;
+    // An executor (pipe.hip) runs the contexts of one LANE on one stream: a lane's batches follow each other in stream order with no
+    // host round trip in between, each in a context of its own (its own pages, scratch and results).  Such a context does not own
+    // its stream, waits for ITS batch's last kernel (batch_event, recorded by the executor) instead of for the whole stream —
+    // the lane's next batch is queued behind it — and reads results back on the lane's side stream (io_stream) for the same reason.
+    bool owns_stream = true;
+    hipStream_t io_stream = nullptr;    // device -> host / device -> device copies of finished results (== stream for a context of its own)
+    hipEvent_t batch_event = nullptr;   // set by the executor behind a batch's last kernel; consumed by the first wait (wait_batch, ctx.hip)
+    bool tail_full_chip = false;        // the executor says nothing scans behind this batch (focr_pipe_end_of_stream / _announce_last): its tail may take every CU (rows2_verify)
     std::string err;
 
     // bank
@@ -330,6 +299,8 @@ void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_t
 void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layouts, bank offsets (host only)
 int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s);  // ctx.hip
 int pages_alt_swap(focr_ctx *c, size_t n_pages, size_t r_w, size_t r_h);
+void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream);  // ctx.hip: the context joins an executor's lane
+int wait_batch(focr_ctx *c);  // ctx.hip: until the context's queued work is done (its batch's event inside an executor, else its stream)
 int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of);  // host only
 
 // ---- device helpers: the reference's f64 epilogue, operation for operation ----

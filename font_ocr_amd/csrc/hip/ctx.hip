@@ -241,6 +241,7 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         c->n_cus = (unsigned)std::max(cus, 1);
         c->chunked_verify = getenv("FOCR_VERIFY_GLOBAL") == nullptr;
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->io_stream = c->stream;
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
         FOCR_HIP(c, hipMalloc(&c->d_counter, COUNTER_BYTES));
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, COUNTER_BYTES, c->stream));
@@ -280,7 +281,7 @@ void focr_ctx_destroy(focr_ctx_t *c) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->launch_events)
         if (ev) (void)hipEventDestroy(ev);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -321,8 +322,8 @@ int focr_debug_force_split(focr_ctx_t *c, int on) {
 int focr_sync(focr_ctx_t *c) {
     if (!c) return FOCR_ERR_INVALID;
     FOCR_HIP(c, hipSetDevice(c->device));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    return finish_results(c);
+    if (c->sizes_pending || c->post_pending) return finish_results(c);  // waits for the batch itself
+    return wait_batch(c);
 }
 
 int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_templates, const uint8_t *needles,
@@ -757,10 +758,37 @@ static int scan_now(focr_ctx *c) {
 
 void row_segments(const focr_ctx *c, uint32_t *seg_shift, uint32_t *n_seg);  // rows.hip
 
+// The context joins a lane of an executor (pipe.hip): it works on the lane's stream from now on (its own, idle, is destroyed) and reads
+// results back on the lane's side stream.
+void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream) {
+    (void)hipSetDevice(c->device);
+    if (c->stream && c->owns_stream && c->stream != lane_stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    c->owns_stream = false;
+    c->stream = lane_stream;
+    c->io_stream = io_stream ? io_stream : lane_stream;
+}
+
+// Until the work this context has queued is done.  Inside an executor that is the context's OWN batch (the event the executor
+// recorded behind its last kernel; consumed here) — the lane's stream already holds the next batch of another context; a context
+// with a stream of its own waits for the stream.
+int wait_batch(focr_ctx *c) {
+    if (c->batch_event) {
+        hipEvent_t e = c->batch_event;
+        c->batch_event = nullptr;
+        FOCR_HIP(c, hipEventSynchronize(e));
+        return FOCR_OK;
+    }
+    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    return FOCR_OK;
+}
+
 int finish_results(focr_ctx *c) {
     if (!c->sizes_pending && !c->post_pending) return FOCR_OK;
     FOCR_HIP(c, hipSetDevice(c->device));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rc = wait_batch(c)) return rc;
     if (c->sizes_pending) {
         c->sizes_pending = false;
         const uint64_t n_cand = c->h_res[0], n_hits = c->h_res[1], total = c->h_res[2];
@@ -899,8 +927,9 @@ int focr_get_counts(focr_ctx_t *c, uint32_t *counts) {
     if (!c->scanned) return fail(c, FOCR_ERR_STATE, "focr_get_counts: no scan results");
     if (int rc = finish_results(c)) return rc;
     FOCR_HIP(c, hipSetDevice(c->device));
-    FOCR_HIP(c, hipMemcpyAsync(counts, c->d_seg_count, c->n_pages * c->n_templates * 4, hipMemcpyDeviceToHost, c->stream));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+    // (finished results are read back on io_stream: inside an executor the context's own stream already holds the lane's next batch)
+    FOCR_HIP(c, hipMemcpyAsync(counts, c->d_seg_count, c->n_pages * c->n_templates * 4, hipMemcpyDeviceToHost, c->io_stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->io_stream));
     return FOCR_OK;
 }
 
@@ -913,11 +942,11 @@ int focr_get_matches(focr_ctx_t *c, uint64_t *offsets, focr_match_t *matches) {
     FOCR_HIP(c, hipSetDevice(c->device));
     if (offsets)
         FOCR_HIP(c, hipMemcpyAsync(offsets, c->d_seg_offset, (c->n_pages * c->n_templates + 1) * 8, hipMemcpyDeviceToHost,
-                                   c->stream));
+                                   c->io_stream));
     if (matches && c->n_matches)
         FOCR_HIP(c, hipMemcpyAsync(matches, c->d_matches, c->n_matches * sizeof(focr_match_t), hipMemcpyDeviceToHost,
-                                   c->stream));
-    FOCR_HIP(c, hipStreamSynchronize(c->stream));
+                                   c->io_stream));
+    FOCR_HIP(c, hipStreamSynchronize(c->io_stream));
     return FOCR_OK;
 }
 

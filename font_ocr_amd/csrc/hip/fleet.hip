@@ -13,7 +13,7 @@
 struct focr_fleet {
     std::vector<int> devices;
     std::vector<focr_pipe_t *> pipes;
-    unsigned lanes = 0;
+    unsigned lanes = 0, slots_per_pipe = 0;  // contexts per device's executor: batches it can hold unreleased
     std::mutex mu;  // serialises submit: tickets are handed out in submission order
     uint64_t next_ticket = 1;
     std::atomic<uint64_t> released{0};  // tickets given back with focr_fleet_release
@@ -61,6 +61,7 @@ int focr_fleet_create(const int *devices, unsigned n_devices, unsigned lanes_per
             focr_fleet_destroy(f);
             return fail(nullptr, rc, msg);
         }
+    f->slots_per_pipe = focr_pipe_contexts(f->pipes[0]);
     *out = f;
     return FOCR_OK;
 }
@@ -74,6 +75,7 @@ void focr_fleet_destroy(focr_fleet_t *f) {
 
 unsigned focr_fleet_devices(const focr_fleet_t *f) { return f ? (unsigned)f->pipes.size() : 0; }
 unsigned focr_fleet_lanes(const focr_fleet_t *f) { return f ? f->lanes : 0; }
+unsigned focr_fleet_slots(const focr_fleet_t *f) { return f ? (unsigned)(f->pipes.size() * f->slots_per_pipe) : 0; }
 focr_pipe_t *focr_fleet_pipe(focr_fleet_t *f, unsigned index) { return f && index < f->pipes.size() ? f->pipes[index] : nullptr; }
 
 int focr_fleet_device_of(const focr_fleet_t *f, uint64_t ticket) {
@@ -97,6 +99,13 @@ int focr_fleet_bank_upload(focr_fleet_t *f, const focr_template_t *templates, si
     return FOCR_OK;
 }
 
+int focr_fleet_announce_last(focr_fleet_t *f) {
+    if (!f) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_announce_last: null fleet");
+    std::lock_guard<std::mutex> lk(f->mu);  // not between a submit's ticket and its pipe
+    for (focr_pipe_t *p : f->pipes) focr_pipe_announce_last(p);  // every device's next batch is its stream's last
+    return FOCR_OK;
+}
+
 int focr_fleet_end_of_stream(focr_fleet_t *f) {
     if (!f) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_end_of_stream: null fleet");
     std::lock_guard<std::mutex> lk(f->mu);  // not between a submit's ticket and its pipe
@@ -115,11 +124,11 @@ int focr_fleet_submit(focr_fleet_t *f, const void *pages, int pages_on_device, s
     if (!f || !ticket) return fail(nullptr, FOCR_ERR_INVALID, "focr_fleet_submit: bad arguments");
     std::lock_guard<std::mutex> lk(f->mu);  // submissions are ordered by definition
     const uint64_t t = f->next_ticket;
-    // Every lane holding an unreleased batch: the lane this batch maps to is the one with the OLDEST ticket, and waiting for it
+    // Every context holding an unreleased batch: the context this batch maps to is the one with the OLDEST ticket, and waiting for it
     // here would be waiting for the caller's own focr_fleet_release — a consumer that submits and retires on one thread would
     // hang with no diagnostic.  Refuse instead (a consumer that releases from a second thread simply submits again).
-    if (t - 1 - f->released.load() >= (uint64_t)f->pipes.size() * f->lanes)
-        return fail(nullptr, FOCR_ERR_STATE, "focr_fleet_submit: every lane holds an unreleased batch; release the oldest ticket first");
+    if (t - 1 - f->released.load() >= (uint64_t)f->pipes.size() * f->slots_per_pipe)
+        return fail(nullptr, FOCR_ERR_STATE, "focr_fleet_submit: every context holds an unreleased batch; release the oldest ticket first");
     uint64_t pt = 0;
     const int rc = focr_pipe_submit(pipe_of(f, t), pages, pages_on_device, n_pages, r_w, r_h, invert, threshold, cap, mode, process_hits, anchor_threshold,
                                     overlap, nullptr, 0, &pt);

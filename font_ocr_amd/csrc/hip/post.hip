@@ -242,11 +242,11 @@ static int fetch_lines(focr_ctx *c) {
     if (c->n_matches && (c->n_lines || c->n_chars)) {
         FOCR_HIP(c, hipSetDevice(c->device));
         if (c->n_lines)
-            FOCR_HIP(c, hipMemcpyAsync(c->h_line_char_off.data(), c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipMemcpyAsync(c->h_page_line_off.data(), c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            FOCR_HIP(c, hipMemcpyAsync(c->h_line_char_off.data(), c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->io_stream));
+        FOCR_HIP(c, hipMemcpyAsync(c->h_page_line_off.data(), c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->io_stream));
         if (c->n_chars)
-            FOCR_HIP(c, hipMemcpyAsync(c->h_chars.data(), c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+            FOCR_HIP(c, hipMemcpyAsync(c->h_chars.data(), c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->io_stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->io_stream));
     }
     c->h_line_char_off[c->n_lines] = c->n_chars;
     c->lines_on_host = true;
@@ -275,10 +275,10 @@ int focr_get_lines_into(focr_ctx_t *c, uint64_t *page_line_offsets, uint64_t *li
     if (rc) return rc;
     FOCR_HIP(c, hipSetDevice(c->device));
     if (c->n_matches && (c->n_lines || c->n_chars)) {
-        if (c->n_lines) FOCR_HIP(c, hipMemcpyAsync(line_char_offsets, c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipMemcpyAsync(page_line_offsets, c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        if (c->n_chars) FOCR_HIP(c, hipMemcpyAsync(chars, c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->stream));
-        FOCR_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->n_lines) FOCR_HIP(c, hipMemcpyAsync(line_char_offsets, c->post_line_off.p, c->n_lines * 8, hipMemcpyDeviceToHost, c->io_stream));
+        FOCR_HIP(c, hipMemcpyAsync(page_line_offsets, c->post_page_off.p, (c->n_pages + 1) * 8, hipMemcpyDeviceToHost, c->io_stream));
+        if (c->n_chars) FOCR_HIP(c, hipMemcpyAsync(chars, c->post_chars.p, c->n_chars * sizeof(focr_hit_t), hipMemcpyDeviceToHost, c->io_stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->io_stream));
     } else {
         for (size_t p = 0; p <= c->n_pages; p++) page_line_offsets[p] = 0;
     }

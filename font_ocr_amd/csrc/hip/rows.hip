@@ -794,9 +794,9 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
     // until the kernel ends, and the next scan launch's workgroups wait for whole CUs (C2, three in flight, one box, alternating:
     // 512 workgroups 32.55 Gpx/s · 64: 32.82 · 32: 31.2 with the scan launch at 1.57 instead of 1.68 ms, but the lane then waits
     // for its verify).  The whole-bank-in-LDS forms only: the chunked verify of large banks keeps the chip (below).
-    // ... unless the host has said that nothing follows this batch (focr_pipe_end_of_stream) — nobody will scan behind it while its
+    // ... unless the host has said that nothing follows this batch (focr_pipe_announce_last / _end_of_stream) — nobody will scan behind it while its
     // tail runs: then the tail takes the chip (the last batch of a run: a 20-step timed region ends 0.7-1.2 ms earlier)
-    const bool nobody_behind = c->turn_gate && c->turn_gate->closing.load(std::memory_order_relaxed) && c->turn_gate->newest.load(std::memory_order_relaxed) == c->turn_ticket;
+    const bool nobody_behind = c->tail_full_chip;
     const unsigned vcus = (c->scan_cus && c->scan_cus < cus && !nobody_behind) ? std::max(cus - c->scan_cus, cus / 16) : cus;
     if (ub_c) {
         const VerifyArgs va = verify_args(c, thr_d);

@@ -798,16 +798,8 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         // contexts' small kernels use the CUs left free by focr_ctx_set_scan_cus.
         if (c->supers.size() > 40) return fail(c, FOCR_ERR_INVALID, "scan_mfma: too many super-classes");
         {
-        // an executor's batches scan in ticket order (TurnGate, common.h): wait for the earlier tickets' scans to be queued
-        struct GatePass {
-            focr_ctx *c;
-            explicit GatePass(focr_ctx *c_) : c(c_) {
-                if (c->turn_gate) c->turn_gate->enter(c->turn_ticket);
-            }
-            ~GatePass() {
-                if (c->turn_gate) c->turn_gate->leave(c->turn_ticket);
-            }
-        } gate_pass(c);
+        // (an executor queues its batches from ONE thread in ticket order, pipe.hip: its scans enter this chain in that order
+        // with no host-side gate; contexts driven by threads of their own take their turn in the order they get here)
         ScanTurns &tn = scan_turns[(unsigned)c->device % 64];
         std::lock_guard<std::mutex> turn(tn.mu);  // held only while enqueueing
         if (!tn.init) {

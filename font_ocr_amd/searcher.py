@@ -280,18 +280,23 @@ class Scanner:
 
 
 class Pipeline:
-    """Batches in flight (focr_pipe_*, include/focr_ncc.h): n contexts on one device with a native worker thread
-    each; submit() hands batches out round-robin, wait() returns the Scanner view of the context holding a batch's
-    results, release() frees that lane for its next batch.  Calls block in native code with the GIL released."""
+    """Batches in flight (focr_pipe_*, include/focr_ncc.h): `n_lanes` streams on one device, `depth` contexts per lane; a batch is
+    queued on the device the moment it is submitted.  submit() hands batches out round-robin over the n_lanes * depth contexts
+    (`scanners`), wait() returns the Scanner view of the context holding a batch's results, release() frees that context for its
+    next batch.  Calls block in native code with the GIL released."""
 
-    def __init__(self, device=0, n_contexts=3):
+    def __init__(self, device=0, n_lanes=3, depth=None):
         self._lib = N.hip()
         h = C.c_void_p()
-        rc = self._lib.focr_pipe_create(int(device), int(n_contexts), C.byref(h))
+        if depth is None:
+            rc = self._lib.focr_pipe_create(int(device), int(n_lanes), C.byref(h))
+        else:
+            rc = self._lib.focr_pipe_create2(int(device), int(n_lanes), int(depth), C.byref(h))
         if rc != 0:
             raise FocrError(self._lib.focr_last_error_global().decode())
         self._h = h
-        self.scanners = [Scanner(device, _borrowed=self._lib.focr_pipe_context(h, i)) for i in range(n_contexts)]
+        self.n_lanes = int(self._lib.focr_pipe_lanes(h))
+        self.scanners = [Scanner(device, _borrowed=self._lib.focr_pipe_context(h, i)) for i in range(int(self._lib.focr_pipe_contexts(h)))]
         self._keep = {}  # ticket -> host array kept alive while its batch is in flight
 
     def close(self):
@@ -359,9 +364,23 @@ class Pipeline:
         self._announced = getattr(self, "_announced", [])
         self._announced.append(luma)  # kept alive until its submit takes over
 
+    def announce_last(self):
+        """focr_pipe_announce_last: the NEXT batch submitted is the stream's last for now: its tail may take the whole GPU."""
+        self._lib.focr_pipe_announce_last(self._h)
+
     def end_of_stream(self):
-        """focr_pipe_end_of_stream: nothing follows the newest batch for now (until the next submit): its tail may take the whole GPU."""
+        """focr_pipe_end_of_stream: nothing follows the newest batch for now — effective only if the executor has not queued that
+        batch yet (say it before the last submit with announce_last)."""
         self._lib.focr_pipe_end_of_stream(self._h)
+
+    def ticket_times(self, ticket):
+        """focr_pipe_ticket_times (after wait, before release): dict of host stamps (us since the executor was created) and the
+        device-side interval to the previous ticket's completion (ms; < 0: not available)."""
+        t = N.TicketTimes()
+        rc = self._lib.focr_pipe_ticket_times(self._h, int(ticket), C.byref(t))
+        if rc != 0:
+            raise FocrError(f"[{rc}] focr_pipe_ticket_times: ticket is not complete and unreleased")
+        return {k: float(getattr(t, k)) for k, _ in N.TicketTimes._fields_}
 
     def wait(self, ticket):
         """Blocks until the batch is done; returns the Scanner whose getters (matches, lines, counts...) see it."""
@@ -410,6 +429,7 @@ class Fleet:
         self._h = h
         self.n_devices = int(self._lib.focr_fleet_devices(h))
         self.lanes = int(self._lib.focr_fleet_lanes(h))
+        self.slots = int(self._lib.focr_fleet_slots(h))  # batches that can be outstanding
         self._views = {}  # context handle -> Scanner view
         self._keep = {}
         self.bank = None

@@ -131,7 +131,8 @@ typedef struct focr_hit {
     uint32_t template_index;
 } focr_hit_t;
 
-/* Context = one device + one stream + all buffers.  One per thread/GPU. */
+/* Context = one device + one stream + all buffers.  One per thread/GPU (the contexts of an executor, focr_pipe_*, share
+ * their lane's stream). */
 int focr_ctx_create(int device, focr_ctx_t **out);
 void focr_ctx_destroy(focr_ctx_t *ctx);
 const char *focr_last_error(const focr_ctx_t *ctx);
@@ -264,61 +265,79 @@ int focr_size_estimate_stats(focr_ctx_t *ctx, uint64_t *redone, double *margin, 
 
 /* ---- batches in flight ---------------------------------------------------
  * The executor form of the page parallelism of src/ncc.rs:839-847 (rayon
- * par_iter over pages): n contexts on one device, one worker thread each;
- * batches are handed out round-robin and complete in submission order (the
- * lanes queue their scan kernels in ticket order).  One batch's small kernels
- * then overlap another's MFMA scan (24 -> 31 Gpx/s at
- * configs[1] with three contexts).  With more than one context the scan kernel
- * of each is capped to 7/8 of the CUs (focr_ctx_set_scan_cus).
+ * par_iter over pages: every worker is kept fed, no central gate).  A device
+ * gets LANES streams (three by default: one batch's small kernels overlap
+ * another's MFMA scan, DESIGN.md section 5: 24 -> 31 Gpx/s at configs[1]) and
+ * every lane a ring of DEPTH contexts (two by default), so LANES x DEPTH
+ * batches can be outstanding.  A batch is queued on the device — all of its
+ * kernels, in ticket order, by one thread of the executor — the moment it is
+ * submitted: batch k + LANES sits behind batch k on their lane's stream while
+ * k still runs and while k's results wait to be read, the scans follow each
+ * other in ticket order through a chain of device events, and no host thread
+ * has to wake up between two batches (a submitting thread that pauses for a few
+ * milliseconds finds the device still busy).  With more than one lane the scan
+ * kernel of each context is capped to 7/8 of the CUs (focr_ctx_set_scan_cus).
  *
- *   focr_pipe_create(dev, 3, &p); focr_pipe_bank_upload(p, ...);
- *   for each batch b:   if (b >= 3) { wait(t[b-3], &ctx); read results from ctx; release(t[b-3]); }
+ *   focr_pipe_create(dev, 3, &p); focr_pipe_bank_upload(p, ...); n = focr_pipe_contexts(p);   // 6
+ *   for each batch b:   if (b >= n) { wait(t[b-n], &ctx); read results from ctx; release(t[b-n]); }
  *                       focr_pipe_submit(p, pages_b, ..., &t[b]);
  *
- * focr_pipe_submit blocks while the lane it maps to (ticket round-robin) still
- * holds an unreleased batch.  pages == NULL rescans the pages already resident
- * in that lane's context (set up through focr_pipe_context).  Host page
- * buffers must stay valid until the batch's focr_pipe_wait returns.  wait and
- * release may be called from a different thread than submit. */
+ * Ticket t (1, 2, 3 ...) runs in context (t - 1) % n, on lane (t - 1) % LANES.
+ * focr_pipe_submit blocks while that context still holds an unreleased batch.
+ * pages == NULL rescans the pages already resident in that context (set up
+ * through focr_pipe_context).  Host page buffers must stay valid until the
+ * batch's focr_pipe_wait returns.  Batches are completed by the thread that
+ * asks for them (wait / host_results / release); these may be called from a
+ * different thread than submit.  Memory: every context holds its own pages,
+ * scratch and results (and a second page set once host pages have gone through
+ * it, see focr_pipe_prefetch) — about 0.6 GB per context at configs[1]. */
 typedef struct focr_pipe focr_pipe_t;
-int focr_pipe_create(int device, unsigned n_contexts, focr_pipe_t **out);
+int focr_pipe_create(int device, unsigned n_lanes, focr_pipe_t **out);  /* DEPTH = 2 (FOCR_PIPE_DEPTH in the environment overrides) */
+int focr_pipe_create2(int device, unsigned n_lanes, unsigned depth, focr_pipe_t **out);  /* 1..8 lanes of 1..4 contexts */
 void focr_pipe_destroy(focr_pipe_t *pipe);
-unsigned focr_pipe_contexts(const focr_pipe_t *pipe);
-focr_ctx_t *focr_pipe_context(focr_pipe_t *pipe, unsigned index);
+unsigned focr_pipe_contexts(const focr_pipe_t *pipe);  /* LANES x DEPTH: batches that can be outstanding */
+unsigned focr_pipe_lanes(const focr_pipe_t *pipe);
+focr_ctx_t *focr_pipe_context(focr_pipe_t *pipe, unsigned index);  /* index < focr_pipe_contexts: the context of tickets index + 1, index + 1 + n, ... */
 int focr_pipe_bank_upload(focr_pipe_t *pipe, const focr_template_t *templates, size_t n_templates,
                           const uint8_t *needles, size_t needles_len);
 /* One batch = pages (host luma8 or, with pages_on_device != 0, a device
  * pointer; NULL = resident) -> focr_scan(threshold, cap, mode) -> if
- * process_hits != 0, focr_process_hits(anchor_threshold, overlap).  If
- * chars_out != NULL (a device buffer of chars_out_bytes) the batch's
- * characters (focr_hit_t[focr_total_chars]) are also copied there on the
- * context's stream before the batch completes, so that the caller can release
- * the lane at once and still hand the characters to a collective;
- * FOCR_ERR_OVERFLOW if they do not fit. */
+ * process_hits != 0, focr_process_hits(anchor_threshold, overlap).  Host pages
+ * cross PCIe on a copy stream of the batch's lane (as if announced with
+ * focr_pipe_prefetch at this moment).  If chars_out != NULL (a device buffer of
+ * chars_out_bytes) the batch's characters (focr_hit_t[focr_total_chars]) are
+ * also copied there when the batch is completed (focr_pipe_wait), so that the
+ * caller can release the context at once and still hand the characters to a
+ * collective; FOCR_ERR_OVERFLOW if they do not fit. */
 int focr_pipe_submit(focr_pipe_t *pipe, const void *pages, int pages_on_device, size_t n_pages, size_t r_w,
                      size_t r_h, int invert, float threshold, uint32_t cap, int mode, int process_hits,
                      float anchor_threshold, int32_t overlap, void *chars_out, size_t chars_out_bytes,
                      uint64_t *ticket);
 /* Announce the host pages of a batch that will be submitted AFTER every batch announced or submitted so far, and start
  * their way to the device now: one DMA into a staging buffer of the lane the batch will run on, then the ingest (inversion,
- * pitched copies) into that lane's ALTERNATE page set, both on a copy stream of the lane — under the scans of the batches in
- * flight, instead of at the head of the batch's own chain of kernels (a lane's chain is what decides whether the scans of
- * consecutive batches follow each other without a gap: DESIGN.md section 5).  When the batch starts, the lane's two page
- * sets change places.  The matching focr_pipe_submit must bring the same pointer (FOCR_ERR_STATE otherwise: announced
- * batches must be submitted in the order they were announced); with another geometry or `invert` the announcement is void
- * and the lane uploads the batch itself.  At most one announcement per lane: with n contexts, announce batch b + n right
- * after submitting batch b.  Page-locked memory (focr_host_alloc) makes the copy asynchronous.  The pages must stay valid
- * and unchanged until that batch's focr_pipe_wait returns.  Optional: a batch that was not announced is uploaded by its
- * lane as before (src/ncc.rs:575, 880-892: the reference decodes and converts inside the page loop). */
+ * pitched copies) into the ALTERNATE page set of the batch's context, both on a copy stream of the lane — under the scans of
+ * the batches in flight, instead of at the head of the batch's own chain of kernels.  When the batch is queued, the context's
+ * two page sets change places.  The matching focr_pipe_submit must bring the same pointer (FOCR_ERR_STATE otherwise:
+ * announced batches must be submitted in the order they were announced); with another geometry or `invert` the announcement
+ * is void and the batch is copied again.  At most one announcement per context: with n = focr_pipe_contexts, announce batch
+ * b + n at the earliest after submitting batch b (blocks until the context's previous announced batch has been queued; the
+ * executor's lock is not held meanwhile).  Page-locked memory (focr_host_alloc) makes the copy asynchronous.  The pages must
+ * stay valid and unchanged until that batch's focr_pipe_wait returns.  One thread announces and submits.  Cost: the second
+ * page set doubles a context's page memory (u8 + int8 copies: 138 MB per 128 pages of 608x720).  Optional: a batch that was
+ * not announced takes the same road when it is submitted (src/ncc.rs:575, 880-892: the reference decodes and converts inside
+ * the page loop). */
 int focr_pipe_prefetch(focr_pipe_t *pipe, const void *pages, size_t n_pages, size_t r_w, size_t r_h, int invert);
-/* Optional hint: nothing will be submitted behind the newest batch for now (the end of the host's input; the next
- * focr_pipe_submit takes the hint back).  The tail kernels of that last batch then take the whole GPU instead of the share the
- * persistent scan kernel of a following batch would leave them — the stream's last results arrive about a millisecond earlier.
- * Call it right after the last submit; results are the same either way. */
+/* Optional hints: nothing will be submitted behind a batch for now (the end of the host's input).  The tail kernels of that last
+ * batch then take the whole GPU instead of the share the persistent scan kernel of a following batch would leave them — the
+ * stream's last results arrive about a millisecond earlier; results are the same either way.  Batches are queued on the device
+ * the moment they are submitted, so say it BEFORE the last submit: focr_pipe_announce_last marks the next batch submitted.
+ * focr_pipe_end_of_stream, called right after the last submit, marks the newest batch if the executor has not queued it yet
+ * (it normally has: kept for hosts that learn of the end only afterwards). */
+int focr_pipe_announce_last(focr_pipe_t *pipe);
 int focr_pipe_end_of_stream(focr_pipe_t *pipe);
-/* Results on the host without touching the context from the consumer's thread: with fetch on, every lane copies its
- * batch's per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory
- * of its own before the batch completes; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out
+/* Results on the host: with fetch on, completing a batch (focr_pipe_host_results / _wait / _release) also copies its
+ * per-(page, template) counts and, if process_hits ran, its lines (focr_get_lines layout) into page-locked memory of its
+ * context, on the lane's side stream; focr_pipe_host_results waits for the batch like focr_pipe_wait and hands out
  * pointers that stay valid until focr_pipe_release.  Set fetch before the first submit. */
 typedef struct focr_host_results {
     const uint32_t *counts;        /* [n_pages][n_templates] */
@@ -333,30 +352,42 @@ int focr_pipe_host_results(focr_pipe_t *pipe, uint64_t ticket, focr_host_results
 /* Blocks until the batch is done; returns its status and the context that
  * holds its results (all getters of this header apply). */
 int focr_pipe_wait(focr_pipe_t *pipe, uint64_t ticket, focr_ctx_t **ctx);
-/* The lane may take its next batch; the results of `ticket` are gone. */
+/* Where a ticket's time went (after its focr_pipe_wait, before its release): host stamps in microseconds since the executor
+ * was created, and the device-side interval between the previous ticket's last kernel and this one's (HIP events; < 0 when the
+ * previous ticket was not available: first ticket, retired out of order).  A host that sees low throughput can tell a late
+ * submit (submit_us far behind the previous ticket's), a late executor (enqueue_*), a slow device (device_gap_ms) and a late
+ * consumer (done_us: when the waiting thread saw the batch complete) apart. */
+typedef struct focr_ticket_times {
+    double submit_us, enqueue_begin_us, scan_queued_us, enqueue_end_us, done_us;
+    float device_gap_ms;
+} focr_ticket_times_t;
+int focr_pipe_ticket_times(focr_pipe_t *pipe, uint64_t ticket, focr_ticket_times_t *out);
+/* The context may take its next batch; the results of `ticket` are gone. */
 int focr_pipe_release(focr_pipe_t *pipe, uint64_t ticket);
 
 /* ---- every GPU of the node ------------------------------------------------
  * The same executor over several devices (the page parallelism of src/ncc.rs:839-847 uses every core the host has; this
  * uses every GPU): one focr_pipe per device, created and given the bank in parallel; batch k (in submission order) goes to
- * device k % n_devices and, there, to the next lane.  Tickets are the fleet's own, 1, 2, 3 ... in submission order; retire
+ * device k % n_devices and, there, to the next context.  Tickets are the fleet's own, 1, 2, 3 ... in submission order; retire
  * them in that order and the output order is the submission order whatever the device count.  No collective: results
  * converge on the host that consumes them (a device-resident consumer uses focr_rccl.h).  `devices` == NULL or
- * n_devices == 0: all visible devices.  At most n_devices * lanes_per_device batches are in flight: with every lane holding
- * an unreleased batch focr_fleet_submit returns FOCR_ERR_STATE ("release the oldest ticket first") instead of waiting for a
- * release that a single-threaded consumer could never make; with pages_on_device != 0 the pointer
- * must belong to focr_fleet_device_of(ticket it will get) — host pages are the normal case.  The `ncc` binary is this
- * loop. */
+ * n_devices == 0: all visible devices.  At most focr_fleet_slots() = n_devices * lanes_per_device * DEPTH batches are
+ * outstanding: with every context holding an unreleased batch focr_fleet_submit returns FOCR_ERR_STATE ("release the oldest
+ * ticket first") instead of waiting for a release that a single-threaded consumer could never make; with
+ * pages_on_device != 0 the pointer must belong to focr_fleet_device_of(ticket it will get) — host pages are the normal case.
+ * The `ncc` binary is this loop. */
 typedef struct focr_fleet focr_fleet_t;
 int focr_fleet_create(const int *devices, unsigned n_devices, unsigned lanes_per_device, focr_fleet_t **out);
 void focr_fleet_destroy(focr_fleet_t *fleet);
 unsigned focr_fleet_devices(const focr_fleet_t *fleet);
 unsigned focr_fleet_lanes(const focr_fleet_t *fleet);
+unsigned focr_fleet_slots(const focr_fleet_t *fleet);  /* batches that can be outstanding over all devices */
 focr_pipe_t *focr_fleet_pipe(focr_fleet_t *fleet, unsigned index);  /* the executor of the index-th device */
 int focr_fleet_device_of(const focr_fleet_t *fleet, uint64_t ticket);  /* HIP device index ticket maps / will map to */
 int focr_fleet_bank_upload(focr_fleet_t *fleet, const focr_template_t *templates, size_t n_templates,
                            const uint8_t *needles, size_t needles_len);
 int focr_fleet_set_fetch(focr_fleet_t *fleet, int on);
+int focr_fleet_announce_last(focr_fleet_t *fleet);  /* the last n_devices batches end their devices' streams: call before submitting them (focr_pipe_announce_last on every executor) */
 int focr_fleet_end_of_stream(focr_fleet_t *fleet);  /* focr_pipe_end_of_stream on every device's executor */
 int focr_fleet_submit(focr_fleet_t *fleet, const void *pages, int pages_on_device, size_t n_pages, size_t r_w, size_t r_h,
                       int invert, float threshold, uint32_t cap, int mode, int process_hits, float anchor_threshold,

@@ -750,39 +750,48 @@ def test_extreme_page_geometry(scanner, bank_x2, mode, shape):
 
 
 def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
-    """focr_pipe_*: the native batches-in-flight executor — tickets complete in order, each batch's lists equal the
-    oracle's, host and resident submissions both work, misuse is reported."""
+    """focr_pipe_*: the native batches-in-flight executor (3 lanes x 2 contexts; every batch queued on the device when it is
+    submitted) — tickets complete in order, each batch's lists equal the oracle's, host and resident submissions both work, the
+    per-ticket stamps are there, misuse is reported."""
     from font_ocr_amd.searcher import FocrError, Pipeline
 
-    n_batches = 7
+    n_batches = 11
     pages = [np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 1200 + 2 * b + p, 280 + 8 * (b % 3), 96) for p in range(2)])
              for b in range(n_batches)]
     want = [_oracle_lists(pg, bank_x2, 0.8, 1024) for pg in pages]
     pipe = Pipeline(0, 3)
     try:
+        n = len(pipe.scanners)  # batches that can be outstanding: lanes x contexts per lane
+        assert pipe.n_lanes == 3 and n == 6
         pipe.set_bank(bank_x2)
         tickets = []
         for b in range(n_batches):
-            if len(tickets) >= 3:
-                t = tickets[b - 3]
+            if len(tickets) >= n:
+                t = tickets[b - n]
                 sc = pipe.wait(t)
                 offsets, m = sc.matches()
-                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - 3], f"batch {b - 3}")
+                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - n], f"batch {b - n}")
                 assert sc.total_chars() > 0
+                tt = pipe.ticket_times(t)
+                assert tt["submit_us"] <= tt["enqueue_begin_us"] <= tt["scan_queued_us"] <= tt["enqueue_end_us"] <= tt["done_us"], tt
+                assert t == 1 or tt["device_gap_ms"] >= 0.0, tt  # retired in order: the previous ticket's last kernel came first
                 pipe.release(t)
+                with pytest.raises(FocrError):
+                    pipe.ticket_times(t)  # released
             tickets.append(pipe.submit(pages[b], 0.8))
         assert tickets == list(range(1, n_batches + 1))
-        for b in range(n_batches - 3, n_batches):
+        for b in range(n_batches - n, n_batches):
             sc = pipe.wait(tickets[b])
             offsets, m = sc.matches()
             _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"batch {b}")
             pipe.release(tickets[b])
-        # resident rescan: ticket 8 maps to lane (8 - 1) % 3 = 1, which last held ticket 5 = batch 4
+        # resident rescan: ticket 12 runs in context (12 - 1) % 6 = 5, which last held ticket 6 = batch 5
         t = pipe.submit(None, 0.8)
-        assert t == 8
+        assert t == n_batches + 1
+        last_b = max(b for b in range(n_batches) if b % n == (t - 1) % n)
         sc = pipe.wait(t)
         offsets, m = sc.matches()
-        _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[4], "resident rescan")
+        _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[last_b], "resident rescan")
         pipe.release(t)
         with pytest.raises(FocrError):
             pipe.release(t)  # already released
@@ -796,7 +805,7 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
     a batch that was not announced (or announced with another inversion) is still uploaded by its lane."""
     from font_ocr_amd.searcher import FocrError, PinnedPages, Pipeline
 
-    n_batches, n_lanes = 8, 3
+    n_batches, n_lanes = 13, 3
     pins = []
     for b in range(n_batches):
         pin = PinnedPages(2, 96, 288)
@@ -807,25 +816,28 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
     pipe = Pipeline(0, n_lanes)
     try:
         pipe.set_bank(bank_x2)
-        for b in range(n_lanes):
+        n = len(pipe.scanners)  # 6 contexts: one announcement each
+        for b in range(n):
             pipe.prefetch(pins[b].array)
         with pytest.raises(FocrError):
-            pipe.prefetch(pins[n_lanes].array)  # every lane already holds an announcement
+            pipe.prefetch(pins[n].array)  # every context already holds an announcement
         with pytest.raises(FocrError):
             pipe.submit(pins[1].array, 0.8)  # batch 0 was announced for this ticket
         tickets = []
         for b in range(n_batches):
-            if len(tickets) >= n_lanes:
-                t = tickets[b - n_lanes]
+            if len(tickets) >= n:
+                t = tickets[b - n]
                 sc = pipe.wait(t)
                 offsets, m = sc.matches()
-                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - n_lanes], f"batch {b - n_lanes}")
+                _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b - n], f"batch {b - n}")
                 pipe.release(t)
+            if b + 1 == n_batches:
+                pipe.announce_last()  # nothing follows the next batch for now: its tail may take the whole chip; same lists
             tickets.append(pipe.submit(pins[b].array, 0.8))
-            if b + n_lanes < n_batches:
-                pipe.prefetch(pins[b + n_lanes].array)
-        pipe.end_of_stream()  # nothing follows for now: the newest batch's tail may take the whole chip; same lists (the next submit takes the hint back)
-        for b in range(n_batches - n_lanes, n_batches):
+            if b + n < n_batches:
+                pipe.prefetch(pins[b + n].array)
+        pipe.end_of_stream()  # the late form of the hint (the batch is normally queued already: no effect); same lists
+        for b in range(n_batches - n, n_batches):
             sc = pipe.wait(tickets[b])
             offsets, m = sc.matches()
             _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[b], f"batch {b}")
@@ -852,7 +864,7 @@ def test_pipeline_prefetch_matches_oracle(bank_x2):
         offsets, m = sc.matches()
         _assert_same(_csr_to_lists(offsets, m, 2, len(bank_x2)), want[2], "batch announced with another inversion")
         pipe.release(t)
-        for b in (3, 4, 5, 6):  # the page sets change places batch after batch on every lane: announced batches only
+        for b in (3, 4, 5, 6, 7, 8, 9, 10):  # the page sets change places batch after batch in every context: announced batches only
             pipe.prefetch(pins[b].array)
             t = pipe.submit(pins[b].array, 0.8)
             sc = pipe.wait(t)
@@ -1102,11 +1114,11 @@ def test_pipeline_soak_mfma_equals_direct():
 def test_fleet_orders_batches_over_devices(bank_x2):
     """focr_fleet_* (the multi-device executor of the C ABI): batch k goes to device k % n_devices; retired in submission order
     the results are those of a single context, whatever the device count.  The one GPU of the test box is listed twice
-    (two executors, four contexts on it), which exercises the ticket arithmetic of a two-device fleet."""
+    (two executors, eight contexts on it), which exercises the ticket arithmetic of a two-device fleet."""
     from font_ocr_amd.searcher import Fleet
 
     bank = bank_x2.subset(list(range(33, 70)) + list(range(95 + 33, 95 + 70)))
-    batches = [synth_pages(bank_x2, 1 + (k % 3), 300, 130, first=9000 + 10 * k) for k in range(9)]
+    batches = [synth_pages(bank_x2, 1 + (k % 3), 300, 130, first=9000 + 10 * k) for k in range(11)]
     want = []
     with Scanner(0) as sc:
         sc.set_bank(bank)
@@ -1119,7 +1131,7 @@ def test_fleet_orders_batches_over_devices(bank_x2):
     for devices in ([0], [0, 0]):
         fl = Fleet(devices, lanes=2)
         try:
-            assert fl.n_devices == len(devices) and fl.lanes == 2
+            assert fl.n_devices == len(devices) and fl.lanes == 2 and fl.slots == 4 * len(devices)
             fl.set_bank(bank)
             inflight, got = [], []
 
@@ -1131,8 +1143,8 @@ def test_fleet_orders_batches_over_devices(bank_x2):
                 fl.release(t)
 
             for k, pg in enumerate(batches):
-                if len(inflight) == fl.n_devices * fl.lanes:
-                    if k == fl.n_devices * fl.lanes:  # every lane holds an unreleased batch: refused, not a silent self-deadlock
+                if len(inflight) == fl.slots:
+                    if k == fl.slots:  # every context holds an unreleased batch: refused, not a silent self-deadlock
                         from font_ocr_amd.searcher import FocrError
 
                         with pytest.raises(FocrError, match="release the oldest"):
