@@ -273,9 +273,9 @@ def main():
     ap.add_argument("--prefilter", choices=["auto", "one", "legacy"], default="auto",
                     help="MFMA prefilter kernel (focr_ctx_set_prefilter): auto = one = threshold planes + scan_mfma2s_kernel; "
                          "legacy = round 1's kernel and int32 threshold tables")
-    ap.add_argument("--tail", choices=["hits", "rows3", "legacy"], default="hits",
+    ap.add_argument("--tail", choices=["hits", "legacy"], default="hits",
                     help="tail of the MFMA scan (focr_ctx_set_row_tail): hits = verify in flush order, then bucket + sort the hits (default); "
-                         "rows3 = round 3's row tail (candidates bucketed + sorted per row, verified, compacted); legacy = round 2's radix-sort tail")
+                         "legacy = round 2's radix-sort tail")
     ap.add_argument("--legacy-tail", action="store_true",
                     help="round 2's tail (library radix sort of all candidates + verify + compaction) instead of the per-row sort + verify (focr_ctx_set_row_tail(0)), for A/B")
     ap.add_argument("--no-column-drop", action="store_true",
@@ -285,6 +285,10 @@ def main():
     ap.add_argument("--noise", action="store_true", help="uniform-random pages instead of synthetic text (worst case: nothing to prune, no hits)")
     ap.add_argument("--with-upload", action="store_true", help="also time steps that start from PAGEABLE host pages, upload and scan back to back (e2e_value_incl_h2d)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the short untimed leg that measures the pipelined PCIe-inclusive rate (e2e_value_incl_h2d_pipelined)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the two optional legs behind the default measurement: c3_value (BASELINE configs[2]'s geometry and 1520-template bank, 64 resident "
+                         "1200x1600 pages per batch) and c4_stream_value (2048 DIFFERENT 608x720 pages streamed through the executor in batches of 128: "
+                         "every batch is new to its context's size estimates).  Never part of `value`")
     ap.add_argument("--dry-launch", action="store_true", help="launcher / timing-protocol self-test on the gloo backend with a stub step: no GPU, not a measurement")
     ap.add_argument("--settle-s", type=float, default=0.8, help="untimed extra warm-up (seconds of steps) before the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
@@ -376,7 +380,7 @@ def main():
             c_.set_column_drop(False)
         if args.legacy_tail:
             args.tail = "legacy"
-        c_.set_row_tail({"hits": 1, "rows3": 2, "legacy": 0}[args.tail])
+        c_.set_row_tail({"hits": 1, "legacy": 0}[args.tail])
     pipe.set_bank(bank)
     scs, pages = [], None
     shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM
@@ -813,7 +817,7 @@ def main():
             "scan_mode": args.mode,
             "prefilter": args.prefilter,
             "column_drop": not args.no_column_drop,
-            "tail": {"hits": "hits-first rows", "rows3": "round-3 rows", "legacy": "legacy radix sort"}[args.tail],
+            "tail": {"hits": "hits-first rows", "legacy": "legacy radix sort"}[args.tail],
             "parallelism": (f"REHEARSAL: {world} ranks on one GPU, gloo gather of match lists" if share_gpu else
                             f"pages sharded over {world} rank(s), RCCL gather of match lists" if world > 1 else "single GPU"),
         },
@@ -959,6 +963,92 @@ def main():
                                   if np.array_equal(dev_counts[:S_], cpu_counts) else "; MISMATCH of per-page counts against the CPU leg")
         except OSError:
             out["parity"] = "golden fixture not found"
+
+    # Two more workloads for the record, after everything the default line needs: BASELINE configs[2]'s geometry and
+    # the streaming form of configs[1].  Optional legs: a failure goes to optional_leg_errors, `value` is never touched.
+    def extra_leg(pipe_, n_warm, n_timed, submit_step, px_per_step):
+        """n_warm untimed + n_timed timed steps through executor pipe_ (same protocol as the headline: drained on both sides);
+        returns (Mpx/s, ms per step, {scan launch -> (avg ms, alg MACs, launches)}, batches redone exact)."""
+        slots = len(pipe_.scanners)
+        jobs_, kern_ = deque(), {}
+        redone0 = sum(c_.size_estimate_stats()["redone"] for c_ in pipe_.scanners)
+
+        def retire_(keep):
+            t_ = jobs_.popleft()
+            c_ = pipe_.wait(t_)
+            if keep:
+                for li in c_.launches():
+                    k_ = kern_.setdefault((li["name"], li["alg_macs"]), [0.0, 0])
+                    k_[0] += li["ms"]
+                    k_[1] += 1
+            pipe_.release(t_)
+
+        def run_(n, keep):
+            for k_ in range(n):
+                if len(jobs_) == slots:
+                    retire_(keep)
+                if k_ + 1 == n:
+                    pipe_.announce_last()
+                jobs_.append(submit_step(k_))
+            while jobs_:
+                retire_(keep)
+            for c_ in pipe_.scanners:
+                c_.sync()
+
+        run_(n_warm, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_(n_timed, True)
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t1
+        redone = sum(c_.size_estimate_stats()["redone"] for c_ in pipe_.scanners) - redone0
+        return px_per_step * n_timed / dt_ / 1e6, dt_ / n_timed * 1e3, kern_, redone
+
+    def leg_roofline(kern_, ms_step):
+        (name_, alg_), (ms_, n_) = max(kern_.items(), key=lambda kv: kv[0][1])
+        step_alg = sum(a_ * v_[1] for (_, a_), v_ in kern_.items()) / max(1, max(v_[1] for v_ in kern_.values()))
+        return {"kernel": name_, "avg_kernel_ms": round(ms_ / n_, 4), "frac": round(2.0 * alg_ / (ms_ / n_ / 1e3) / 1e12 / PEAK_I8_MFMA_TOPS, 4),
+                "frac_whole_step": round(2.0 * step_alg / (ms_step / 1e3) / 1e12 / PEAK_I8_MFMA_TOPS, 4)}
+
+    if rank == 0 and world == 1 and args.config == "c2" and not args.noise and not args.no_extra_legs and not use_dist and mode == SCAN_MFMA:
+        try:  # c4_stream: 2048 different pages, HBM-resident as luma8, ingested device -> device batch by batch (one DMA-free pass per 16 steps)
+            n_stream = 2048
+            stream_dev = torch.from_numpy(synth_pages(bank, n_stream, R_W, R_H, first=100000)).to(dev)
+            nb_ = n_stream // P
+            val_, ms_, kern_, redone_ = extra_leg(pipe, nb_, 2 * nb_,
+                                                  lambda k_: pipe.submit(None, args.threshold, 1024, mode, True, 0.95, 5, device_ptr=stream_dev[(k_ % nb_) * P].data_ptr(), shape=(P, R_H, R_W)),
+                                                  P * R_W * R_H)
+            out["c4_stream_value"] = round(val_, 2)
+            out["c4_stream"] = dict(leg_roofline(kern_, ms_), ms_per_step=round(ms_, 4), steps=2 * nb_, pages=n_stream, batches_redone_exact=redone_,
+                                    note=f"BASELINE configs[3]'s stream on one GPU: {n_stream} different synthetic pages resident in HBM as luma8, scanned in batches of {P} "
+                                         "(ingest + scan + process_hits per step), two passes timed behind one untimed pass; every batch differs from the one its context "
+                                         "scanned before, so the size estimates run at their working margin (redone = batches scanned a second time with exact sizes)")
+            del stream_dev
+        except Exception as e:  # noqa: BLE001
+            leg_errors["c4_stream_value"] = repr(e)
+        try:  # c3: BASELINE configs[2]'s geometry and bank on an executor of its own
+            bank3 = Bank.load(os.path.join(ROOT, "tests", "golden", "bank_dejavu13_ascii95_x2y2.bin"))
+            P3, W3, H3 = 64, 1200, 1600
+            pipe3 = Pipeline(local_rank, n_lanes, max(1, args.depth))
+            try:
+                pipe3.set_bank(bank3)
+                pg3 = torch.from_numpy(synth_pages(bank3, P3, W3, H3, first=200000)).to(dev)
+                for c_ in pipe3.scanners:  # the same 64 pages resident in every context (rescanned every step, as the headline does)
+                    c_.set_scan_cus(scan_cus)
+                    c_.alloc_pages(P3, W3, H3)
+                    c_.upload_pages_device(pg3.data_ptr(), P3, 0, invert=True)
+                    c_.sync()
+                del pg3
+                val_, ms_, kern_, redone_ = extra_leg(pipe3, 2 * len(pipe3.scanners), 12,
+                                                      lambda k_: pipe3.submit(None, args.threshold, 1024, mode, True, 0.95, 5), P3 * W3 * H3)
+                out["c3_value"] = round(val_, 2)
+                out["c3"] = dict(leg_roofline(kern_, ms_), ms_per_step=round(ms_, 4), steps=12, pages_per_batch=P3, templates=len(bank3), batches_redone_exact=redone_,
+                                 note="BASELINE configs[2]'s geometry: batches of 64 synthetic 1200x1600 pages, 95-glyph bank, --x-bits 2 --y-bits 2 (1520 templates in four "
+                                      "size classes: two scan launches per batch, the exact verify in chunk passes), threshold 0.8, + process_hits; 12 timed steps")
+            finally:
+                pipe3.close()
+        except Exception as e:  # noqa: BLE001
+            leg_errors["c3_value"] = repr(e)
 
     if leg_errors:
         out["optional_leg_errors"] = leg_errors

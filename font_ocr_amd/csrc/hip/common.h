@@ -75,11 +75,11 @@ struct KeyFmt {
     __host__ __device__ uint64_t line(uint64_t k) const { return k >> (bt + bx); }  // (page << by) | y
 };
 
-// Candidate counts per BUCKET for the row path of the tail (rows.hip).  A bucket is a page row cut into n_seg segments of
+// The BUCKETS of the row path of the tail (rows.hip).  A bucket is a page row cut into n_seg segments of
 // 2^seg_shift pixels (x >> seg_shift): one segment for narrow pages and small banks, more where a whole row would hold
 // more candidates than one wave sorts in LDS (BASELINE configs[2]: 1200-px rows x 1520 templates).  Buckets ascend with the
-// key: (page, y, x-segment).  Every candidate a wave flushes counts towards its bucket — one no-return atomic per distinct
-// bucket among the flushed keys.  cnt == nullptr: off.
+// key: (page, y, x-segment).  (cnt: round 3's tail counted every flushed candidate towards its bucket in the scan kernels' flush
+// path; always null since round 5 — the hits-first tail counts hits, in the verify.)
 struct RowHist {
     uint32_t *cnt;       // [sub_np * r_h * n_seg], zeroed at the start of the scan
     uint32_t r_h;
@@ -164,6 +164,7 @@ struct focr_ctx {
     int scan_mode = 0;
     int32_t post_overlap = 0;
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
+    uint32_t dbg_grid_num = 0, dbg_grid_den = 0;  // tests: the tail's persistent kernels on num / den times their workgroups (focr_debug_set_tail_grid; 0: as designed)
     int prefilter = 0;                          // FOCR_PREFILTER_*: auto / plane kernel / legacy kernel (focr_ctx_set_prefilter)
     uint16_t *d_planes = nullptr;               // threshold planes, f16: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
     size_t planes_bytes = 0;
@@ -243,13 +244,13 @@ struct focr_ctx {
     DevBuf scan_flags, scan_pos, scan_live, scan_live_list;
     // row path of the tail (rows.hip): candidates bucketed by page row, sorted + verified per row
     focr::RowHist row_hist{};   // what the scan kernels' flush path counts into (cnt == nullptr: legacy tail)
-    DevBuf rows_cnt, rows_base, rows_fill, rows_hits, rows_hbase, rows_big;
+    DevBuf rows_hits, rows_hbase, rows_big;
     uint32_t row_cap = 0;       // per-row candidate capacity the row kernel was instantiated for in the last scan
     uint32_t est_row_max = 0;   // largest row of the previous scan of this setup (estimated mode picks the capacity from it)
     uint32_t row_seg_shift = 0; // log2 of the x-segment width of the buckets (0: not chosen yet for this setup; rows.hip, row_segments)
     bool chunked_verify = true; // hits-first tail, banks above the LDS: verify in chunk passes (false: template rows gathered from global memory; FOCR_VERIFY_GLOBAL, A/B)
     int tail_mode = 1;          // focr_ctx_set_row_tail(): 0 = the legacy tail (radix sort + verify + compaction), 1 = hits-first row tail
-                                // (verify in flush order, hits bucketed + sorted: the default), 2 = round 3's row tail (sort, verify, compact)
+                                // (verify in flush order, hits bucketed + sorted: the default)
     DevBuf ord_k2, ord_k2_alt, ord_v, ord_v_alt, ord_keep;
     DevBuf acc_matches, acc_seg_count, acc_hkeys, acc_hsims;  // split-batch mode: results appended sub-batch by sub-batch
     DevBuf post_line_be;

@@ -120,7 +120,7 @@ static void free_results(focr_ctx *c) {
     c->scan_live.release();
     c->scan_live_list.release();
     for (auto *b : {&c->ord_k2, &c->ord_k2_alt, &c->ord_v, &c->ord_v_alt, &c->ord_keep, &c->acc_matches, &c->acc_seg_count,
-                    &c->acc_hkeys, &c->acc_hsims, &c->rows_cnt, &c->rows_base, &c->rows_fill, &c->rows_hits, &c->rows_hbase, &c->rows_big})
+                    &c->acc_hkeys, &c->acc_hsims, &c->rows_hits, &c->rows_hbase, &c->rows_big})
         b->release();
     free_dev(c->d_L);
     free_dev(c->d_planes);
@@ -300,7 +300,7 @@ int focr_ctx_set_prefilter(focr_ctx_t *c, int mode) {
 
 int focr_ctx_set_row_tail(focr_ctx_t *c, int on) {
     if (!c) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: null context");
-    if (on < 0 || on > 2) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: 0 (legacy tail), 1 (hits-first row tail, the default) or 2 (round 3's row tail)");
+    if (on < 0 || on > 1) return fail(c, FOCR_ERR_INVALID, "focr_ctx_set_row_tail: 0 (legacy tail) or 1 (hits-first row tail, the default)");
     c->tail_mode = on;
     c->est_row_max = 0;
     c->est_cand = c->est_hits = 0;  // the next scan runs with exact sizes
@@ -316,6 +316,13 @@ int focr_ctx_set_column_drop(focr_ctx_t *c, int on) {
 int focr_debug_force_split(focr_ctx_t *c, int on) {
     if (!c) return FOCR_ERR_INVALID;
     c->force_split = on != 0;
+    return FOCR_OK;
+}
+
+int focr_debug_set_tail_grid(focr_ctx_t *c, uint32_t num, uint32_t den) {
+    if (!c) return FOCR_ERR_INVALID;
+    c->dbg_grid_num = num;
+    c->dbg_grid_den = den;
     return FOCR_OK;
 }
 

@@ -305,7 +305,7 @@ struct VerifyArgs {
     unsigned long long *flags_word;           // d_res[4]: bit 2 = a key outside those bounds was met (internal error, never a fault)
 };
 VerifyArgs verify_args(const focr_ctx *c, double thr_d);  // scan_mfma.hip
-// LDS: the whole of needles16 is staged in LDS at `lds` (rows.hip, verify_flat_kernel) — a compile-time choice, so that every
+// LDS: the whole of needles16 is staged in LDS at `lds` (rows.hip, verify_list_kernel) — a compile-time choice, so that every
 // template-row load is a plain ds_read or a plain global load, never a per-lane choice between address spaces
 template <bool LDS>
 __device__ __forceinline__ bool verify_candidate_t(uint64_t key, const VerifyArgs &va, const v4i *lds, float *sim_out) {
@@ -401,7 +401,7 @@ __device__ __forceinline__ bool verify_candidate_meta(uint64_t key, const Verify
 }
 // The same for banks whose templates are all at most 12 px wide: template rows of 12 bytes (three dwords) from LDS, page rows as
 // 12-byte loads, eight in flight — half the LDS and half the registers of the 16-byte form, so that TWO 1 024-thread workgroups
-// share a CU (verify_flat_kernel<2>, rows.hip).  Same arithmetic, same order of operations.
+// share a CU (verify_list_kernel<2>, rows.hip).  Same arithmetic, same order of operations.
 typedef int v3i __attribute__((ext_vector_type(3)));
 typedef v3i v3i_b1 __attribute__((aligned(1)));
 __device__ __forceinline__ bool verify_candidate_narrow(uint64_t key, const VerifyArgs &va, const uint32_t *lds_rows, const VerifyMeta *meta, float *sim_out) {

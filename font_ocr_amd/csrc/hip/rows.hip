@@ -1,29 +1,31 @@
-// rows.hip — the row path of the scan's tail: candidates -> sorted, verified hits, without a global sort.
+// rows.hip — the hits-first row tail of the MFMA scan: candidates -> sorted, verified hits, without a global sort.
 //
 // The prefilter leaves an unordered list of candidate keys (page, y, x, t).  The reference's order (process_hits order:
 // page, y, x, template; src/ncc.rs:741-752) used to be restored by a 5-pass radix sort of all candidates, followed by the
-// exact verify, a flag scan and a compaction (12 launches, ~0.5 ms alone on the chip at BASELINE configs[1]).  But a
-// candidate's (page, y) is one of only sub_np * r_h page rows (92 160 at configs[1], ~50 candidates each), so candidates are
-// BUCKETED by page row — by a segment of 2^k pixels of a page row where rows are wide and banks large (row_segments below;
-// "row" in the names of this file means such a bucket) — and everything after that is per bucket:
+// exact verify, a flag scan and a compaction (12 launches, ~0.5 ms alone on the chip at BASELINE configs[1]: the legacy tail,
+// still in scan_mfma.hip for banks this file does not cover).  But four candidates in ten fall to the verify, the verify needs
+// no sorted input — it needs neighbouring lanes on neighbouring windows, and the scan kernels' flush order has that: the 64 keys
+// of a flush are 64 adjacent windows of one page row — and a hit's (page, y) is one of only sub_np * r_h page rows (92 160 at
+// configs[1]).  So the candidates are verified where they lie and only the HITS are bucketed by page row — by a segment of 2^k
+// pixels of a page row where rows are wide and banks large (row_segments below; "row" in the names of this file means such a
+// bucket) — and sorted per bucket:
 //
-//   scan kernels      every flushed candidate also counts towards its bucket               (flush_wave_candidates, RowHist)
-//   row_prefix        exclusive prefix of the bucket counts -> base, the largest bucket     1 workgroup
-//   row_scatter       candidate -> base[bucket] + (next free slot of the bucket)            order inside a bucket: arbitrary
-//   row_sort          one WAVE per bucket: <= 64 keys ranked in registers by lane-to-lane comparison; else the sub-keys (x, t)
-//                     in registers, counting sort by x in wave-private LDS, rank inside the x-bin by t — back in place.
-//                     Buckets above 1024 go onto a list and through a second launch (capacity 4096, one wave per workgroup)
-//   verify_flat       the reference arithmetic on every candidate (verify_candidate_meta, mfma_common.h), one thread each:
-//                     the bucket-ordered list is dense, neighbouring lanes read the same page lines; template rows and
-//                     records come from LDS; it also counts the hits of every bucket
-//   row_prefix        exclusive prefix of the buckets' hit counts -> the dense position of every bucket's hits, the hit total
-//   row_compact       one wave per bucket: the survivors, order kept, to dense (key, similarity) arrays in (page, y, x, t)
-//                     order — what order.hip takes over
+//   verify_list       the reference arithmetic on every candidate in FLUSH order (verify_candidate_*, mfma_common.h), template rows
+//   / verify_chunks   and records from LDS (in chunk passes for banks above it); a hit takes the next free slot of its bucket (one
+//                     returning atomic per distinct bucket among the wave's hits) — similarity + slot in place; the kernel's last
+//                     workgroup turns the buckets' hit counts into their dense positions, the hit total and the largest bucket
+//   hit_scatter       hit -> hbase[bucket] + slot: the dense (key, similarity) arrays in bucket order, arbitrary inside a bucket
+//   row_sort          one WAVE per bucket, keys with their similarities, in place: <= 64 keys ranked in registers by lane-to-lane
+//                     comparison; else the sub-keys (x, t) in registers, counting sort by x in wave-private LDS, rank inside the
+//                     x-bin by t.  Buckets above 1024 go onto a list and through a second launch (capacity 4096) -> (page, y, x, t)
+//                     order: what order.hip takes over
 //
-// Seven small launches, no library sort, no sentinel pre-fill of the candidate buffer.  A bucket above 4096 candidates (very
-// low thresholds), banks with templates taller than 32 px or more than 4096 templates: the legacy tail (scan_mfma.hip: radix
-// sort + verify_kernel + compaction).  Exact mode knows the largest bucket before it chooses; estimated mode goes by the
-// previous scan's, and a bucket that turns out too large sets the overflow bit: the batch is redone with exact sizes.
+// Three launches (+ the second capacity class of the sort where such a bucket is expected), no counting in the scan kernels' flush
+// path, every pass behind the verify touches hits only.  A bucket above 4096 hits (very low thresholds): the placed hits go
+// through the library radix sort; banks with templates taller than 32 px or more than 4096 templates: the legacy tail.  Exact
+// mode knows the largest bucket before it chooses; estimated mode goes by the previous scan's, and a bucket that turns out too
+// large sets the overflow bit: the batch is redone with exact sizes.  (Round 3's row tail — candidates bucketed, sorted, verified,
+// compacted: seven launches — was kept for A/B through round 4; its last commit is 5ed8d3e.)
 #include "mfma_common.h"
 
 namespace focr {
@@ -140,35 +142,6 @@ __device__ __forceinline__ bool last_workgroup(uint32_t *done) {
         if (threadIdx.x == 0) *done = 0;  // zero between launches (and zeroed with the scan's counters anyway)
     }
     return is_last != 0;
-}
-
-// candidate -> its row's slots.  The candidate list is in flush order: the 64 keys of a wave come from a dozen rows, and
-// neighbouring waves fill the same rows, whose cursors share cache lines — so the wave adds once per distinct row (leader
-// lane, count of its peers) instead of once per candidate.
-__global__ __launch_bounds__(256) void row_scatter_kernel(const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p,
-                                                          unsigned long long cap, const RowHist rows, const uint32_t *__restrict__ base,
-                                                          uint32_t *__restrict__ fill, uint64_t *__restrict__ bucket) {
-    const unsigned long long n = min(*n_cand_p, cap);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {  // wave-uniform trip count
-        const unsigned long long i = i0 + lane;
-        const bool valid = i < n;
-        const uint64_t key = valid ? cand[i] : 0;
-        const uint32_t r = valid ? row_of_key(key, rows) : 0xffffffffu;
-        uint32_t slot = 0;
-        uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
-        while (todo) {  // one pass per distinct row among the wave's keys
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
-            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
-            uint32_t first = 0;
-            if (lane == (int)__builtin_ctzll(peers)) first = atomicAdd(fill + r0, (uint32_t)__builtin_popcountll(peers));
-            first = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(peers));
-            if (r == r0) slot = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-            todo &= ~peers;
-        }
-        if (valid) bucket[(size_t)base[r] + slot] = key;  // slot < cnt[r]: every stored candidate was counted
-    }
 }
 
 // Sort every row's candidates by (x, t) — the low bt + bx bits of the key, unique inside a row — in place.  One WAVE per row
@@ -297,106 +270,13 @@ __global__ __launch_bounds__(WAVES * 64) void row_sort_kernel(uint32_t n_rows, c
     }
 }
 
-// exact verify, one thread per candidate of the row-ordered list (perfectly balanced); similarity + emit flag in place.
-// A candidate costs 15 page-row loads (neighbouring lanes: neighbouring windows, a few cache lines per wave instruction) and
-// 15 template-row loads — a 64-way GATHER per wave instruction when they come from global memory, which kept the texture
-// addresser busy for most of the kernel's time (round 2: 0.22 ms for 3.8 M candidates).  LDS = true: the bank's verify
-// operand (16 bytes per template row) is staged in LDS once per workgroup — when all of it fits 144 KiB (BASELINE
-// configs[1]: 380 templates, 91 KB); larger banks keep the global loads (LDS = false).
-// MODE 0: template rows from global memory · 1: from LDS, 16 bytes each · 2: from LDS, 12 bytes each (every template at most 12 px
-// wide and the whole operand within half a CU's LDS): 64 VGPRs, two workgroups per CU — the kernel waits on memory four fifths of
-// its time, and in flight it has only the CUs the scan leaves free, so waves per CU are what it runs on.
-template <int MODE>
-__global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_flat_kernel(
-    const uint64_t *__restrict__ bucket, const uint32_t *__restrict__ total_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
-    float *__restrict__ bsims, uint8_t *__restrict__ bflags, uint32_t *__restrict__ row_hits) {
-    // LDS: [template records: n_templates x 32 B][template rows, 16 B (MODE 1) or 12 B (MODE 2) each]
-    extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
-    constexpr bool LDS = MODE == 1;
-    VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
-    v4i *needle_lds = verify_lds + 2 * va.n_templates;
-    uint32_t *needle12 = reinterpret_cast<uint32_t *>(needle_lds);
-    for (uint32_t i = threadIdx.x; i < 2 * va.n_templates; i += blockDim.x) verify_lds[i] = reinterpret_cast<const v4i *>(va.vmeta)[i];
-    if (MODE == 1)
-        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) needle_lds[i] = va.needles16[i];
-    if (MODE == 2)
-        for (uint32_t i = threadIdx.x; i < lds_rows; i += blockDim.x) {
-            const v4i r = va.needles16[i];
-            needle12[3 * i] = (uint32_t)r[0], needle12[3 * i + 1] = (uint32_t)r[1], needle12[3 * i + 2] = (uint32_t)r[2];
-        }
-    __syncthreads();
-    const unsigned long long n = min((unsigned long long)*total_p, cap);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
-    uint64_t key_next = first + lane < n ? bucket[first + lane] : 0;  // the next step's key is loaded a step ahead
-    for (unsigned long long i0 = first; i0 < n; i0 += stride) {  // wave-uniform trip count
-        const unsigned long long i = i0 + lane;
-        const bool valid = i < n;
-        const uint64_t key = key_next;
-        if (i + stride < n) key_next = bucket[i + stride];
-        float sim = 0.f;
-        const bool emit = valid && (MODE == 2 ? verify_candidate_narrow(key, va, needle12, meta, &sim) : verify_candidate_meta<LDS>(key, va, needle_lds, meta, &sim));
-        if (valid) {
-            bsims[i] = sim;
-            bflags[i] = emit ? 1 : 0;
-        }
-        // hits per page row: the wave's 64 consecutive candidates belong to one row, rarely two or three
-        const uint32_t r = emit ? row_of_key(key, rows) : 0xffffffffu;
-        uint64_t todo = __builtin_amdgcn_ballot_w64(emit);
-        while (todo) {
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(todo));
-            const uint64_t peers = __builtin_amdgcn_ballot_w64(r == r0);
-            if (lane == (int)__builtin_ctzll(peers)) atomicAdd(row_hits + r0, (uint32_t)__builtin_popcountll(peers));
-            todo &= ~peers;
-        }
-    }
-}
-
-// survivors of every row, order kept, to their dense places: hbase[r] (exclusive prefix of the rows' hit counts) + rank inside
-// the row.  One wave per row.
-__global__ __launch_bounds__(256) void row_compact_kernel(uint32_t n_rows, const uint32_t *__restrict__ base, const uint32_t *__restrict__ fill,
-                                                          const uint32_t *__restrict__ hbase, const uint64_t *__restrict__ bucket,
-                                                          const float *__restrict__ bsims, const uint8_t *__restrict__ bflags, uint64_t *__restrict__ hkeys,
-                                                          float *__restrict__ hsims, unsigned long long hit_cap) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = gridDim.x * 4;
-    for (uint32_t r = wave; r < n_rows; r += n_waves) {
-        const uint32_t n = fill[r];
-        if (n == 0) continue;
-        const size_t b = base[r];
-        size_t dst = hbase[r];
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            const bool emit = j < n && bflags[b + j];
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
-            if (emit) {
-                const size_t pos = dst + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (pos < hit_cap) {  // estimated sizes: a hit count above its bound is flagged by record_scan_sizes and redone
-                    hkeys[pos] = bucket[b + j];
-                    hsims[pos] = bsims[b + j];
-                }
-            }
-            dst += (size_t)__builtin_popcountll(mask);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The hits-first tail (round 4).  The row tail above sorts every CANDIDATE before it is verified, although four in ten are
-// thrown away by the verify (BASELINE configs[1]: 4.53 M candidates, 2.72 M hits per batch; configs[2]: 48.9 M / 26.0 M), and
-// moves them three times (scatter, sort, compaction).  The verify does not need sorted input — it needs neighbouring lanes on
-// neighbouring windows, and the scan kernels' flush order gives that already: the 64 keys of a flush come from one item, i.e.
-// 64 adjacent windows of one page row.  So:
-//
-//   verify_list       the reference arithmetic on every candidate in FLUSH order; a hit takes the next free slot of its
-//                     bucket (one returning atomic per distinct bucket among the wave's hits) — similarity + slot in place
-//   row_prefix        exclusive prefix of the buckets' hit counts -> the dense position of every bucket, hit total, largest bucket
-//   hit_scatter       hit -> hbase[bucket] + slot: the dense (key, similarity) arrays in bucket order, arbitrary inside a bucket
-//   row_sort<PAY>     one wave per bucket, keys with their similarities, in place -> (page, y, x, t) order: what order.hip takes over
-//
-// Four launches (+ the second capacity class of the sort) instead of seven, no counting in the scan kernels' flush path, and
-// every pass behind the verify touches hits only.
+// The exact verify of the candidate list in flush order.  A candidate costs 15 page-row loads (neighbouring lanes: neighbouring
+// windows, a few cache lines per wave instruction) and 15 template-row loads — a 64-way GATHER per wave instruction when they come
+// from global memory, which kept the texture addresser busy for most of the kernel's time (round 2: 0.22 ms for 3.8 M candidates).
+// MODE 0: template rows from global memory · 1: the bank's verify operand staged in LDS once per workgroup, 16 bytes per row (all
+// of it fits 144 KiB) · 2: 12 bytes per row (every template at most 12 px wide and the whole operand within half a CU's LDS): 64
+// VGPRs, two workgroups per CU — the kernel waits on memory four fifths of its time, and in flight it has only the CUs the scan
+// leaves free, so waves per CU are what it runs on.
 template <int MODE>
 __global__ __launch_bounds__(VERIFY_THREADS, MODE == 2 ? 8 : 1) void verify_list_kernel(
     const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, uint32_t lds_rows, const RowHist rows,
@@ -464,23 +344,26 @@ struct ChunkTable {
     uint32_t n;
     uint32_t t_lo[MAX_VERIFY_CHUNKS + 1];    // chunk k: templates [t_lo[k], t_lo[k + 1])
     uint32_t row_lo[MAX_VERIFY_CHUNKS + 1];  // ... rows [row_lo[k], row_lo[k + 1]) of d_vrows_t
-    uint32_t max_templates, max_rows;        // of any chunk (LDS layout)
+    // LDS layout, per chunk: [its records: 32 B each][its rows]; behind the LARGEST chunk's data (data_bytes, a multiple of 16) the
+    // waves' queues.  (Round 4 laid the rows out behind the largest chunk's RECORDS and sized the data for the largest record count
+    // plus the largest row count — two maxima that can come from different chunks: a bank of many short templates followed by
+    // tall ones asked for more LDS than a CU has although every chunk fitted.)
+    uint32_t data_bytes;
 };
 template <int ROWB>
 __global__ __launch_bounds__(VERIFY_THREADS, 4) void verify_chunks_kernel(
     const uint64_t *__restrict__ cand, const unsigned long long *__restrict__ n_cand_p, unsigned long long cap, const VerifyArgs va, const ChunkTable ct,
     const uint32_t *__restrict__ vrows_t, const VerifyMeta *__restrict__ vmeta_t, const RowHist rows, float *__restrict__ sims, uint32_t *__restrict__ slots,
     uint32_t *__restrict__ row_hits, const TailWork tw) {
-    // LDS: [chunk records: max_templates x 32 B][chunk rows: max_rows x ROWB][per wave: CHUNK_QUEUE keys, CHUNK_QUEUE list positions]
+    // LDS: [the chunk's records: 32 B each][the chunk's rows: ROWB each] ... at data_bytes: [per wave: CHUNK_QUEUE keys][per wave: CHUNK_QUEUE list positions]
     extern __shared__ __attribute__((aligned(16))) v4i verify_lds[];
     __shared__ uint32_t wave_sum[16], wave_max[16];
     constexpr uint32_t ROWDW = ROWB / 4;
     VerifyMeta *meta = reinterpret_cast<VerifyMeta *>(verify_lds);
-    uint32_t *rows_lds = reinterpret_cast<uint32_t *>(verify_lds + 2 * ct.max_templates);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t *q_key = reinterpret_cast<uint64_t *>(rows_lds + (size_t)((ct.max_rows * ROWDW + 3) & ~3u)) + (size_t)wv * CHUNK_QUEUE;
-    uint32_t *q_pos = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(rows_lds + (size_t)((ct.max_rows * ROWDW + 3) & ~3u)) + (size_t)(VERIFY_THREADS / 64) * CHUNK_QUEUE) +
-                      (size_t)wv * CHUNK_QUEUE;
+    uint64_t *q_base = reinterpret_cast<uint64_t *>(verify_lds + ct.data_bytes / 16);
+    uint64_t *q_key = q_base + (size_t)wv * CHUNK_QUEUE;
+    uint32_t *q_pos = reinterpret_cast<uint32_t *>(q_base + (size_t)(VERIFY_THREADS / 64) * CHUNK_QUEUE) + (size_t)wv * CHUNK_QUEUE;
     const unsigned long long n = min(*n_cand_p, cap);
     // the wave's own piece of the list: whole groups of 64
     const unsigned long long n_waves = (unsigned long long)gridDim.x * (VERIFY_THREADS / 64);
@@ -509,13 +392,14 @@ __global__ __launch_bounds__(VERIFY_THREADS, 4) void verify_chunks_kernel(
             if (r == r0) slot = start + __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             todo &= ~peers;
         }
-        if (valid) {
+        if (valid && pos < n) {  // (pos comes out of the wave's own queue: always below n — the test costs nothing and a write never leaves the arrays)
             sims[pos] = sim;
             slots[pos] = slot;
         }
     };
     for (uint32_t k = 0; k < ct.n; k++) {
         const uint32_t t_lo = ct.t_lo[k], t_hi = ct.t_lo[k + 1], row_lo = ct.row_lo[k], n_rows_c = ct.row_lo[k + 1] - row_lo;
+        uint32_t *rows_lds = reinterpret_cast<uint32_t *>(verify_lds + 2 * (t_hi - t_lo));  // behind THIS chunk's records
         __syncthreads();  // the previous chunk's readers are done
         for (uint32_t i = threadIdx.x; i < 2 * (t_hi - t_lo); i += VERIFY_THREADS) verify_lds[i] = reinterpret_cast<const v4i *>(vmeta_t + t_lo)[i];
         for (uint32_t i = threadIdx.x; i < n_rows_c * ROWDW; i += VERIFY_THREADS) rows_lds[i] = vrows_t[(size_t)row_lo * ROWDW + i];
@@ -616,7 +500,7 @@ static size_t row_buckets(const focr_ctx *c) {
 }
 
 bool rows_applicable(const focr_ctx *c) {
-    if (c->tail_mode == 0) return false;
+    if (c->tail_mode == 0) return false;  // focr_ctx_set_row_tail(0): the legacy tail, for A/B
     for (const SizeClass &sc : c->classes)
         if (sc.tall) return false;  // scan_tall_kernel appends its candidates without counting them per bucket
     static_assert(sizeof(VerifyMeta) == 32, "VerifyMeta is staged in LDS as two 16-byte words per template");
@@ -639,128 +523,13 @@ int rows2_begin(focr_ctx *c, ClearList &clear) {
     return FOCR_OK;
 }
 
-// before the scan kernels: zeroed row counters + what the flush path needs to find a key's row
-int rows_begin(focr_ctx *c, ClearList &clear) {
-    const size_t n_rows = row_buckets(c);  // "rows" below: buckets = page rows x x-segments
-    const size_t padded = (n_rows + 1 + 3) / 4 * 4 + 4;  // row_prefix_kernel moves 16 bytes at a time
-    uint32_t *cnt = (uint32_t *)c->rows_cnt.ensure(c, padded * 4);
-    if (!cnt || !c->rows_base.ensure(c, padded * 4) || !c->rows_fill.ensure(c, padded * 4) || !c->rows_hits.ensure(c, padded * 4) ||
-        !c->rows_hbase.ensure(c, padded * 4))
-        return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    uint32_t *big = (uint32_t *)c->rows_big.ensure(c, ((size_t)n_rows + 1) * 4 + 8);  // [0]: length of the list of large buckets (rows_tail)
-    if (!big) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    if (!clear.add(cnt, padded * 4)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
-    if (!clear.add(c->rows_hits.p, padded * 4)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");  // the padding behind the last row must read 0
-    if (!clear.add(big, 8)) return fail(c, FOCR_ERR_INVALID, "rows: clear list full or region too large");
-    uint32_t seg_shift, n_seg;
-    row_segments(c, &seg_shift, &n_seg);
-    c->row_hist = RowHist{cnt, (uint32_t)c->r_h, c->fmt.bt + c->fmt.bx, c->fmt.by, (uint32_t)c->sub_p0, c->fmt.bt, c->fmt.bx, seg_shift, n_seg};
-    return FOCR_OK;
-}
-
-// right after the scan kernels: row_base, cursors cleared, the largest row -> d_res[5]
-int rows_prefix(focr_ctx *c) {
-    const uint32_t n_rows = (uint32_t)row_buckets(c);
-    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)c->rows_cnt.p, n_rows, (uint32_t *)c->rows_base.p,
-                       (uint32_t *)c->rows_fill.p, (uint64_t *)nullptr, c->d_res + 5);
-    FOCR_HIP(c, hipGetLastError());
-    return FOCR_OK;
-}
-
 uint32_t rows_capacity_for(uint64_t row_max) { return row_max <= 4096 ? 4096u : 0u; }  // rows above 1024 take the second sort launch
 
-// scatter, per-row sort + verify, compaction: leaves the dense sorted hits in d_hit_keys / d_hit_sims_alt and their number in
-// d_res[6]; records ev[3] behind the verify
-int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class, bool big_expected) {
-    const uint32_t n_rows = (uint32_t)row_buckets(c);
-    int rc;
-    if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
-    if (c->cand_alt_capacity < c->cand_capacity) {
-        FOCR_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->d_cand_alt) (void)hipFree(c->d_cand_alt);
-        c->d_cand_alt = nullptr;
-        c->cand_alt_capacity = 0;
-        if (hipMalloc(&c->d_cand_alt, c->cand_capacity * 8) != hipSuccess) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-        c->cand_alt_capacity = c->cand_capacity;
-    }
-    float *bsims = (float *)c->scan_pos.ensure(c, (ub_c + 1) * 4);
-    if (!bsims) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    const unsigned cus = c->n_cus;
-    const uint32_t *base = (const uint32_t *)c->rows_base.p;
-    uint32_t *fill = (uint32_t *)c->rows_fill.p, *hits = (uint32_t *)c->rows_hits.p, *hbase = (uint32_t *)c->rows_hbase.p;
-    if (ub_c) {
-        const unsigned nb = (unsigned)std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16);
-        hipLaunchKernelGGL(row_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, c->d_cand, n_cand_p, (unsigned long long)ub_c, c->row_hist, base, fill,
-                           c->d_cand_alt);
-        FOCR_HIP(c, hipGetLastError());
-    }
-    const VerifyArgs va = verify_args(c, thr_d);
-    unsigned long long *flags_word = (unsigned long long *)(c->d_res + 4);
-    uint8_t *bflags = (uint8_t *)c->scan_flags.ensure(c, ub_c + 16);
-    if (!bflags) return fail(c, FOCR_ERR_NOMEM, "rows: hipMalloc failed");
-    const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
-    {
-        const uint32_t seg_w = 1u << c->row_hist.seg_shift;
-        uint32_t xs = 0;
-        while ((seg_w >> xs) > XBINS) xs++;
-        const uint32_t n_bins = seg_w >> xs;
-        uint32_t *big = (uint32_t *)c->rows_big.p;  // allocated and zeroed in rows_begin
-        auto k1 = row_sort_kernel<1024, 4, false, false>;
-        auto k2 = row_sort_kernel<4096, 1, true, false>;
-        const size_t lds1 = (size_t)4 * (XBINS + 1 + 1024) * 4, lds2 = (size_t)(XBINS + 1 + 4096) * 4;
-        hipLaunchKernelGGL(k1, dim3(row_blocks), dim3(256), lds1, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt,
-                           seg_w - 1, xs, n_bins, big, flags_word, (float *)nullptr, ~0ull);
-        FOCR_HIP(c, hipGetLastError());
-        // the buckets above 1 024 keys (the list `big`): one wave each over the whole chip where the last scan of this setup had any
-        // (or the exact count says so), else ONE wave — it still sorts whatever turns up, but a launch of `cus` single-wave
-        // workgroups that find an empty list cost 60 us of a lane's time in flight
-        hipLaunchKernelGGL(k2, dim3(big_expected ? cus : 1u), dim3(64), lds2, c->stream, n_rows, base, (const uint32_t *)fill, c->d_cand_alt, c->fmt.bt + c->fmt.bx, c->fmt.bt, seg_w - 1, xs, n_bins,
-                           big, flags_word, (float *)nullptr, ~0ull);
-        FOCR_HIP(c, hipGetLastError());
-    }
-    if (ub_c) {
-        // the verify operand in LDS if all of it fits: as 12-byte rows with two workgroups per CU when every template is at most
-        // 12 px wide and meta + rows take no more than half of the LDS, else as 16-byte rows, else from global memory
-        size_t all_rows = 0;
-        uint32_t max_w = 0;
-        for (const TemplateConst &tc : c->h_tconst) {
-            all_rows += (size_t)tc.n_h * (tc.n_w > 16 ? 2u : 1u);
-            max_w = std::max<uint32_t>(max_w, tc.n_w);
-        }
-        const size_t meta_bytes = c->n_templates * sizeof(VerifyMeta);  // <= 4096 templates here: 128 KiB at most
-        const bool narrow = max_w <= 12 && meta_bytes + all_rows * 12 <= ((size_t)80 << 10) - 256;
-        const bool in_lds = meta_bytes + all_rows * 16 <= ((size_t)144 << 10);
-        const size_t lds = meta_bytes + (narrow ? all_rows * 12 : in_lds ? all_rows * 16 : 0);
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
-        if (narrow) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<2>, dim3(std::max(1u, std::min<unsigned>((unsigned)((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS), 2 * cus))), dim3(VERIFY_THREADS), lds,
-                               c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va, (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
-        } else if (in_lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<1>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c, va,
-                               (uint32_t)all_rows, c->row_hist, bsims, bflags, hits);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_flat_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(verify_flat_kernel<0>, dim3(nb * (meta_bytes > ((size_t)64 << 10) ? 1 : 2)), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand_alt, base + n_rows, (unsigned long long)ub_c,
-                               va, 0u, c->row_hist, bsims, bflags, hits);
-        }
-        FOCR_HIP(c, hipGetLastError());
-    }
-    FOCR_HIP(c, hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(row_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)hits, n_rows, hbase, (uint32_t *)nullptr, c->d_res + 6,
-                       (uint64_t *)nullptr);
-    FOCR_HIP(c, hipGetLastError());
-    {
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
-        hipLaunchKernelGGL(row_compact_kernel, dim3(nb), dim3(256), 0, c->stream, n_rows, base, (const uint32_t *)fill, (const uint32_t *)hbase,
-                           (const uint64_t *)c->d_cand_alt, (const float *)bsims, (const uint8_t *)bflags, c->d_hit_keys, c->d_hit_sims_alt,
-                           (unsigned long long)c->hit_capacity);
-        FOCR_HIP(c, hipGetLastError());
-    }
-    return FOCR_OK;
+// test hook (focr_debug_set_tail_grid): the persistent tail kernels' grids scaled by num / den — results must not depend on a grid
+static unsigned tail_grid(const focr_ctx *c, unsigned blocks) {
+    if (!c->dbg_grid_num || !c->dbg_grid_den) return blocks;
+    return (unsigned)std::max<uint64_t>(1, (uint64_t)blocks * c->dbg_grid_num / c->dbg_grid_den);
 }
-
 
 // The verify operand's place for this bank: 2 = 12-byte rows in LDS, two workgroups per CU; 1 = 16-byte rows in LDS; 0 = global memory
 static int verify_mode(const focr_ctx *c, size_t *lds, uint32_t *rows_out) {
@@ -821,8 +590,7 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
                     }
                     ct.t_lo[ct.n] = t0;
                     ct.row_lo[ct.n] = c->h_vrow0_t[t0];
-                    ct.max_templates = std::max(ct.max_templates, t - t0);
-                    ct.max_rows = std::max(ct.max_rows, c->h_vrow0_t[t] - c->h_vrow0_t[t0]);
+                    ct.data_bytes = std::max(ct.data_bytes, (uint32_t)((bytes + 15) & ~(size_t)15));  // this chunk's records + rows (bytes <= budget)
                     ct.n++;
                     t0 = t;
                     bytes = 0;
@@ -832,12 +600,14 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
             if (ok) {
                 ct.t_lo[ct.n] = (uint32_t)c->n_templates;
                 ct.row_lo[ct.n] = c->h_vrow0_t[c->n_templates];
-                const size_t lds_c = (size_t)ct.max_templates * sizeof(VerifyMeta) + (((size_t)ct.max_rows * (c->vrow_bytes / 4) + 3) & ~(size_t)3) * 4 + queue_bytes;
+                const size_t lds_c = (size_t)ct.data_bytes + queue_bytes;  // <= 150 KiB by construction: every chunk's data is within the budget
                 // one workgroup per CU of the whole chip: at configs[2] the chunk passes are a fifth of a lane's chain, and the lane
                 // waits for them (half / a third / a quarter of the CUs: 7.25 / 7.21 / 7.12 Gpx/s against 7.28)
-                const unsigned nbc = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus));
+                const unsigned nbc = tail_grid(c, (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)cus)));
+                hipError_t attr = hipSuccess;
 #define FOCR_VERIFY_CHUNKS(R)                                                                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_chunks_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);                 \
+    attr = hipFuncSetAttribute(reinterpret_cast<const void *>(verify_chunks_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);                \
+    if (attr == hipSuccess)                                                                                                                                    \
     hipLaunchKernelGGL(verify_chunks_kernel<R>, dim3(nbc), dim3(VERIFY_THREADS), lds_c, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
                        ct, (const uint32_t *)c->d_vrows_t, (const VerifyMeta *)c->d_vmeta_t, c->row_hist, csims, cslots, hits, tw)
                 if (narrow) {
@@ -846,12 +616,15 @@ int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, 
                     FOCR_VERIFY_CHUNKS(16);
                 }
 #undef FOCR_VERIFY_CHUNKS
-                FOCR_HIP(c, hipGetLastError());
-                goto verified;
+                if (attr == hipSuccess) {
+                    FOCR_HIP(c, hipGetLastError());
+                    goto verified;
+                }
+                (void)hipGetLastError();  // the device refuses that much LDS: the rows come from global memory instead (below)
             }
         }
         const unsigned per_cu = mode == 2 ? 2u : (mode == 0 && c->n_templates * sizeof(VerifyMeta) <= ((size_t)64 << 10) ? 2u : 1u);
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)vcus * per_cu));
+        const unsigned nb = tail_grid(c, (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + VERIFY_THREADS - 1) / VERIFY_THREADS, (size_t)vcus * per_cu)));
 #define FOCR_VERIFY_LIST(M)                                                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(verify_list_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL(verify_list_kernel<M>, dim3(nb), dim3(VERIFY_THREADS), lds, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, va, \
@@ -884,14 +657,14 @@ int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, si
     const unsigned cus = c->n_cus;
     const uint32_t *hits = (const uint32_t *)c->rows_hits.p, *hbase = (const uint32_t *)c->rows_hbase.p;
     if (ub_c) {
-        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16));
+        const unsigned nb = tail_grid(c, (unsigned)std::max<size_t>(1, std::min<size_t>((ub_c + 255) / 256, (size_t)cus * 16)));
         hipLaunchKernelGGL(hit_scatter_kernel, dim3(nb), dim3(256), 0, c->stream, (const uint64_t *)c->d_cand, n_cand_p, (unsigned long long)ub_c, c->row_hist, hbase,
                            (const float *)c->scan_pos.p, (const uint32_t *)c->scan_flags.p, c->d_hit_keys, c->d_hit_sims_alt, (unsigned long long)c->hit_capacity);
         FOCR_HIP(c, hipGetLastError());
     }
     if (!sort) return FOCR_OK;  // a bucket beyond the row sort's capacity (exact sizes know): the caller sorts the placed hits with the library sort
     unsigned long long *flags_word = (unsigned long long *)(c->d_res + 4);
-    const unsigned row_blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8));
+    const unsigned row_blocks = tail_grid(c, (unsigned)std::max<size_t>(1, std::min<size_t>(((size_t)n_rows + 3) / 4, (size_t)cus * 8)));
     const uint32_t seg_w = 1u << c->row_hist.seg_shift;
     uint32_t xs = 0;
     while ((seg_w >> xs) > XBINS) xs++;

@@ -22,10 +22,10 @@
 //     the f64 roundings of the exact formula.  Classes 9 or 13 px wide leave their last column to a second Cauchy-Schwarz term,
 //     L(w) = kappa * norm_p(w) - c * rho_max * dnorm(w), and take the next narrower K layout (column drop, mfma_common.h).  The
 //     filter has no false negatives (host model of the device arithmetic: prefilter_model.hip, tests/test_prefilter_host.py).
-//     Survivors go to a candidate list, counted per page-row bucket on the way.
-//  3. the row tail (rows.hip): candidates bucketed by page row, sorted per bucket, verified exactly — the reference formula,
-//     operation for operation (verify_candidate, mfma_common.h / common.h) — and compacted; order.hip derives the per-call
-//     ranks and the cap.  (verify_kernel below + the library radix sort = the legacy tail, kept as a fallback.)
+//     Survivors go to a candidate list.
+//  3. the hits-first row tail (rows.hip): candidates verified exactly where they lie — the reference formula, operation for
+//     operation (verify_candidate, mfma_common.h / common.h) — hits bucketed by page row and sorted per bucket; order.hip derives
+//     the per-call ranks and the cap.  (verify_kernel below + the library radix sort = the legacy tail, kept as a fallback.)
 //
 // Sizes: every phase behind the scan kernel takes its element count from device memory; exact / estimated mode: see
 // launch_scan_mfma and ctx.hip (finish_results).
@@ -52,10 +52,7 @@ int compact_candidates(focr_ctx *c, const uint64_t *keys, const float *sims, con
 int order_sorted_hits(focr_ctx *c, uint64_t *hkeys, float *hsims, const uint64_t *n_p, size_t ub, const unsigned long long *n_cand_p, size_t ub_c);
 // rows.hip: the row path of the tail
 bool rows_applicable(const focr_ctx *c);
-int rows_begin(focr_ctx *c, ClearList &clear);
-int rows_prefix(focr_ctx *c);
 uint32_t rows_capacity_for(uint64_t row_max);
-int rows_tail(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c, uint32_t cap_class, bool big_expected);
 int rows2_begin(focr_ctx *c, ClearList &clear);  // the hits-first tail (rows.hip): verify in flush order, then only hits are placed and sorted
 int rows2_verify(focr_ctx *c, double thr_d, const unsigned long long *n_cand_p, size_t ub_c);
 int rows2_place(focr_ctx *c, const unsigned long long *n_cand_p, size_t ub_c, size_t ub_h, bool big_expected, bool sort);
@@ -690,8 +687,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             use_rows = c->est_row_max != 0 && row_cap != 0;
         }
         c->row_hist = RowHist{};
-        const bool hits_first = use_rows && c->tail_mode == 1;  // verify in flush order, only hits are bucketed and sorted (rows.hip)
-        if (use_rows && (rc = hits_first ? rows2_begin(c, clear) : rows_begin(c, clear))) return rc;
+        if (use_rows && (rc = rows2_begin(c, clear))) return rc;  // hits-first row tail: verify in flush order, only hits are bucketed and sorted (rows.hip)
         // legacy tail, estimated sizes: unused candidate slots hold the largest key so that the radix sort leaves them at the end
         if (c->estimated && !use_rows) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
         FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
@@ -891,20 +887,13 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         FOCR_HIP(c, hipMemcpyAsync(c->h_live, c->d_counter + 8, 40 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         const unsigned long long *n_cand_p = (const unsigned long long *)c->d_counter + 1;
         size_t ub_c = c->ub_cand;
-        if (use_rows && !hits_first && !nothing && (rc = rows_prefix(c))) return rc;
         if (nothing) use_rows = false;
         // buckets above the row sort's first capacity class get a second launch (rows.hip): estimated sizes go by the previous scan's largest + 25 %
         bool big_expected = (uint64_t)c->est_row_max + c->est_row_max / 4 + 16 > 1024;
         if (!c->estimated) {
-            unsigned long long n_cand = 0, row_max = 0;
+            unsigned long long n_cand = 0;
             FOCR_HIP(c, hipMemcpyAsync(&n_cand, n_cand_p, 8, hipMemcpyDeviceToHost, c->stream));
-            if (use_rows && !hits_first) FOCR_HIP(c, hipMemcpyAsync(&row_max, c->d_res + 5, 8, hipMemcpyDeviceToHost, c->stream));
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
-            if (use_rows && !hits_first) {
-                row_cap = rows_capacity_for(row_max);
-                use_rows = row_cap != 0;  // a row beyond the largest capacity: legacy tail for this scan
-                big_expected = row_max > 1024;
-            }
             if (n_cand > c->cand_capacity) {
                 if (n_cand > ((unsigned long long)1 << 31)) return fail(c, FOCR_ERR_OVERFLOW, "scan_mfma: more than 2^31 candidates in one pass");
                 want_cand = (size_t)n_cand + (size_t)n_cand / 8 + 1024;
@@ -912,7 +901,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             }
             ub_c = (size_t)n_cand;
         }
-        if (use_rows && hits_first) {
+        if (use_rows) {
             // 3a'. hits-first row path: verify the candidates where they lie, then bucket + sort the hits only (rows.hip)
             if ((rc = rows2_verify(c, thr_d, n_cand_p, ub_c))) return rc;
             size_t ub_h = std::min(ub_c, c->est_hits);
@@ -932,19 +921,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             if (!sort_rows && (rc = sort_pairs_u64_f32(c, c->d_hit_keys, c->d_hit_keys_alt, c->d_hit_sims_alt, c->d_hit_sims, ub_h, c->fmt.bits()))) return rc;
             return order_sorted_hits(c, c->d_hit_keys, c->d_hit_sims_alt, c->d_res + 6, ub_h, n_cand_p, ub_c);
         }
-        c->row_cap = use_rows ? row_cap : 0;
-        if (use_rows) {
-            // 3a. row path: bucket by page row, sort + verify per row, compact (rows.hip), then the ordering pass
-            if ((rc = rows_tail(c, thr_d, n_cand_p, ub_c, row_cap, big_expected))) return rc;
-            size_t ub_h = std::min(ub_c, c->est_hits);
-            if (!c->estimated) {  // exact number of hits for the ordering pass
-                uint64_t hits = 0;
-                FOCR_HIP(c, hipMemcpyAsync(&hits, c->d_res + 6, 8, hipMemcpyDeviceToHost, c->stream));
-                FOCR_HIP(c, hipStreamSynchronize(c->stream));
-                ub_h = (size_t)hits;
-            }
-            return order_sorted_hits(c, c->d_hit_keys, c->d_hit_sims_alt, c->d_res + 6, ub_h, n_cand_p, ub_c);
-        }
+        c->row_cap = 0;
         // 3b. legacy tail: sort the candidates into emission order, verify them exactly in place, compact + cap (order.hip)
         if ((rc = ensure_hit_capacity(c, std::max<size_t>(c->hit_capacity, ub_c + 1)))) return rc;
         uint64_t *flags = (uint64_t *)c->scan_flags.ensure(c, (ub_c + 1) * 8);

@@ -175,8 +175,7 @@ class Scanner:
         self._ck(self._lib.focr_ctx_set_prefilter(self._h, int(prefilter)))
 
     def set_row_tail(self, on):
-        """focr_ctx_set_row_tail: True / 1 = hits-first row tail (default), 2 = round 3's row tail (sort, verify, compact),
-        False / 0 = the legacy radix-sort tail; results never change."""
+        """focr_ctx_set_row_tail: True / 1 = hits-first row tail (default), False / 0 = the legacy radix-sort tail; results never change."""
         self._ck(self._lib.focr_ctx_set_row_tail(self._h, int(on)))
 
     def set_column_drop(self, on):
@@ -197,6 +196,10 @@ class Scanner:
     def force_split(self, on):
         """Test hook (focr_debug_force_split): scan the batch in page sub-ranges as after a candidate overflow."""
         self._ck(self._lib.focr_debug_force_split(self._h, int(bool(on))))
+
+    def set_tail_grid(self, num, den):
+        """Test hook (focr_debug_set_tail_grid): the tail's persistent kernels on num / den times their workgroups (0, 0: as designed)."""
+        self._ck(self._lib.focr_debug_set_tail_grid(self._h, int(num), int(den)))
 
     def set_scan_cus(self, max_cus):
         """Upper bound on the CUs the persistent scan kernel occupies (0 = all)."""

@@ -243,10 +243,9 @@ int focr_ctx_set_column_drop(focr_ctx_t *ctx, int on);
 
 /* Tail of the MFMA scan (rows.hip).  1 (default) = the hits-first row path: the candidates are verified where the scan kernels
  * left them (flush order: neighbouring lanes, neighbouring windows), then only the HITS are bucketed by page row and sorted
- * per bucket with their similarities.  2 = round 3's row path (candidates bucketed and sorted per row, then verified, then
- * compacted), kept for A/B.  0 = the legacy tail (library radix sort of all candidates, verify, flag scan, compaction), which
- * also serves batches the row paths do not cover (banks with templates taller than 32 px or more than 4096 templates).
- * Results are identical in every mode. */
+ * per bucket with their similarities.  0 = the legacy tail (library radix sort of all candidates, verify, flag scan, compaction), which
+ * also serves batches the row path does not cover (banks with templates taller than 32 px or more than 4096 templates).
+ * Results are identical in either mode. */
 int focr_ctx_set_row_tail(focr_ctx_t *ctx, int mode);
 
 /* Result sizes.  Every phase behind the scan kernel takes its element count from device memory.  A scan of the same
@@ -419,6 +418,10 @@ int focr_debug_rnorm(focr_ctx_t *ctx, const uint32_t *s, const uint64_t *s2, con
 /* Test hook: make focr_scan take its candidate-overflow fallback (the batch scanned in page sub-ranges and appended)
  * without waiting for an overflow. */
 int focr_debug_force_split(focr_ctx_t *ctx, int on);
+
+/* Test hook: launch the persistent kernels of the scan's tail (exact verify in its list and chunk forms, hit scatter, row sort) on
+ * num / den times the workgroups they are designed for (0 / 0: as designed).  Results must be identical for every grid. */
+int focr_debug_set_tail_grid(focr_ctx_t *ctx, uint32_t num, uint32_t den);
 
 /* Host model of the MFMA prefilter's bound (no device needed; used by the CPU tests, tests/test_prefilter_host.py): builds
  * the quantised bank exactly as focr_bank_upload does and evaluates, for n_windows caller-supplied ink-high patches of

@@ -252,9 +252,9 @@ def test_full_size_c2_properties(scanner, bank_x2):
         assert res[SCAN_DIRECT][2].tobytes() == res[mode][2].tobytes()
     # the price of the bound: more candidates for verify to reject, the same hits (about 1.2 x)
     assert cand[FULL] < cand[MFMA1] < 1.5 * cand[FULL], cand
-    # the tail: the hits-first row path (rows.hip, the default: the scans above) against the legacy radix-sort tail and round 3's
-    # row path (sort, verify, compact), each with exact and with estimated sizes
-    for tail in (0, 2, 1):
+    # the tail: the hits-first row path (rows.hip, the default: the scans above) against the legacy radix-sort tail, each with
+    # exact and with estimated sizes
+    for tail in (0, 1):
         scanner.set_row_tail(tail)
         scanner.scan(0.8, 1024, MFMA1)  # first scan after the switch: exact sizes
         assert np.array_equal(scanner.counts(), res[SCAN_DIRECT][0]) and scanner.matches()[1].tobytes() == res[SCAN_DIRECT][2].tobytes(), tail
@@ -365,12 +365,14 @@ def test_c5_256_template_gemm_variant(scanner, bank_x2):
 
 
 def _random_bank(rng, shapes, per_shape):
-    """A bank of random-noise / structured templates with the given (n_w, n_h) shapes (several size classes)."""
+    """A bank of random-noise / structured templates with the given (n_w, n_h) shapes (several size classes); per_shape: templates
+    per shape (one number, or one per shape)."""
     from font_ocr_amd.bank import TEMPLATE_DTYPE, Bank
 
     tm, needles, off = [], [], 0
-    for (w, h) in shapes:
-        for k in range(per_shape):
+    counts = per_shape if isinstance(per_shape, (list, tuple)) else [per_shape] * len(shapes)
+    for (w, h), n_of_shape in zip(shapes, counts):
+        for k in range(n_of_shape):
             if k % 3 == 0:
                 nd = rng.integers(0, 256, (h, w), dtype=np.uint8)
             elif k % 3 == 1:  # sparse strokes
@@ -422,7 +424,7 @@ def test_random_banks_all_layouts(scanner, mode, shapes):
 def test_banks_above_the_lds_verify_in_chunks(scanner, shapes, per_shape):
     """Round 4: a bank whose verify operand does not fit the LDS whole (here 180 KB of 16-byte rows / 330 KB of 12-byte rows) is
     verified in chunk passes (verify_chunks_kernel, rows.hip: chunk rows in LDS, a wave-private queue per chunk); same lists as
-    the reference kernel, also through round 3's row tail (template rows gathered from global memory)."""
+    the reference kernel, also through the legacy tail (template rows gathered from global memory)."""
     import zlib
 
     rng = np.random.default_rng(zlib.crc32(str(shapes).encode()))
@@ -436,13 +438,72 @@ def test_banks_above_the_lds_verify_in_chunks(scanner, shapes, per_shape):
     scanner.set_bank(bank)
     scanner.set_pages(pages)
     want = _oracle_lists(pages, bank, 0.6, 1024)
-    for tail in (1, 2, 1):
+    for tail in (1, 0, 1):
         scanner.set_row_tail(tail)
         scanner.scan(0.6, 1024, MFMA1)
         offsets, m = scanner.matches()
         _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), want, f"{shapes} tail={tail}")
     names = [li["name"] for li in scanner.launches()]
     assert names, names
+
+
+def test_chunk_layout_when_the_maxima_come_from_different_chunks(scanner):
+    """a bank ordered by template height — about a thousand 8-px-tall templates, then three hundred 32-px-tall ones.  Every
+    chunk of the verify fits the LDS budget, but the chunk with the most RECORDS (the short templates) and the chunk with the most
+    ROWS (the tall ones) are different chunks: round 4 sized the LDS for both maxima at once (175 904 B > 160 KB: the launch failed
+    and with it the batch).  The layout is per chunk now; the lists equal the direct scan's and the reference kernel's."""
+    rng = np.random.default_rng(20260105)
+    bank = _random_bank(rng, [(8, 8), (12, 32)], [1007, 310])
+    pages = rng.integers(0, 256, (2, 70, 120), dtype=np.uint8)
+    pages[rng.random(pages.shape) < 0.5] = 255
+    for k, t in enumerate(range(0, len(bank), 13)):
+        nd = bank.needle(t)
+        y, x = 1 + (5 * k) % (70 - nd.shape[0]), 1 + (13 * k) % (120 - nd.shape[1])
+        pages[k % 2, y:y + nd.shape[0], x:x + nd.shape[1]] = 255 - nd
+    scanner.set_bank(bank)
+    scanner.set_pages(pages)
+    scanner.scan(0.6, 1024, SCAN_DIRECT)
+    want = (scanner.counts().copy(), scanner.matches()[1].tobytes())
+    assert want[0].sum() > 200
+    for _ in range(2):  # exact sizes, then estimated
+        scanner.scan(0.6, 1024, MFMA1)
+        assert np.array_equal(scanner.counts(), want[0]) and scanner.matches()[1].tobytes() == want[1]
+    offsets, m = scanner.matches()
+    _assert_same(_csr_to_lists(offsets, m, 2, len(bank)), _oracle_lists(pages, bank, 0.6, 1024), "short then tall templates")
+
+
+def test_chunked_verify_on_other_grids_and_with_shrinking_estimates(scanner, bank_x2y2):
+    """round 4 recorded a GPU memory access fault in a run that launched the chunked verify (banks above the LDS:
+    BASELINE configs[2]'s 1 520 templates) on 2 / 4 / 8 times its workgroups.  The kernel's indexing does not depend on its grid
+    ("the fault"); this runs it — and the other persistent kernels of the tail — on a quarter, three and eight times their
+    workgroups (focr_debug_set_tail_grid), with exact sizes, with estimated sizes, and with estimates taken from a batch that had
+    many more candidates (the list shrinks under its bound): the lists are the direct scan's every time."""
+    dense = synth_pages(bank_x2y2, 3, 420, 200, first=7100)
+    sparse = dense.copy()
+    sparse[:, 60:, :] = 255  # the same geometry with a quarter of the text
+    scanner.set_bank(bank_x2y2)
+    want = {}
+    for name, pg in (("dense", dense), ("sparse", sparse)):
+        scanner.set_pages(pg)
+        scanner.scan(0.8, 1024, SCAN_DIRECT)
+        scanner.process_hits(0.95, 5)
+        want[name] = (scanner.counts().copy(), scanner.matches()[1].tobytes(), scanner.lines_flat().tobytes())
+    assert want["dense"][0].sum() > 4 * want["sparse"][0].sum() > 1000
+    redone0 = scanner.size_estimate_stats()["redone"]
+    try:
+        for num, den in ((1, 4), (3, 1), (8, 1), (0, 0)):
+            scanner.set_tail_grid(num, den)
+            for name, pg in (("dense", dense), ("dense", None), ("sparse", sparse), ("sparse", None), ("dense", dense)):
+                if pg is not None:
+                    scanner.set_pages(pg)  # same geometry: the size estimates of the previous batch carry over
+                scanner.scan(0.8, 1024, MFMA1)
+                scanner.process_hits(0.95, 5)
+                got = (scanner.counts().copy(), scanner.matches()[1].tobytes(), scanner.lines_flat().tobytes())
+                assert np.array_equal(got[0], want[name][0]) and got[1] == want[name][1] and got[2] == want[name][2], (num, den, name)
+        # sparse -> dense overflows the estimate once per grid (redone exact, the same lists); dense -> sparse runs on the larger bound
+        assert scanner.size_estimate_stats()["redone"] - redone0 <= 8
+    finally:
+        scanner.set_tail_grid(0, 0)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -591,7 +652,7 @@ def test_fuzz_geometry_banks_thresholds(scanner):
         thr = float(rng.choice([-0.5, 0.1, 0.4, 0.8, 0.97]))
         cap = int(rng.choice([1, 2, 37, 1024]))
         scanner.set_column_drop(True)
-        scanner.set_row_tail((1, 2, 0)[it % 3])  # hits-first row tail, round 3's row tail, the legacy tail in turn
+        scanner.set_row_tail((1, 1, 0)[it % 3])  # the hits-first row tail, now and then the legacy tail
         scanner.set_bank(bank)
         scanner.set_pages(pages)
         want = _oracle_lists(pages, bank, thr, cap)

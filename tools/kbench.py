@@ -12,7 +12,7 @@ pages = synth_pages(bank, P, 1200 if C3 else 608, 1600 if C3 else 720)
 sc = Scanner(0); sc.set_bank(bank); sc.set_pages(pages)
 sc.set_prefilter(int(os.environ.get("KB_PREFILTER", "0")))
 if os.environ.get("KB_LEGACY_TAIL"): sc.set_row_tail(0)
-if os.environ.get("KB_TAIL"): sc.set_row_tail(int(os.environ["KB_TAIL"]))  # 1 = hits-first (default), 2 = round 3's row tail, 0 = legacy
+if os.environ.get("KB_TAIL"): sc.set_row_tail(int(os.environ["KB_TAIL"]))  # 1 = hits-first (default), 0 = legacy
 if os.environ.get("KB_SCAN_CUS"): sc.set_scan_cus(int(os.environ["KB_SCAN_CUS"]))
 for _ in range(2): sc.scan(0.8, 1024, SCAN_MFMA)
 acc = {}
