@@ -159,7 +159,7 @@ struct focr_ctx {
     // the next scan's bounds are the last counts + 3 x this, between 4 % and 20 % (finish_results)
     double est_var = 0.0667;
     uint64_t est_last_cand = 0, est_last_hits = 0;
-    uint64_t est_sig = 0, bank_gen = 0, counters_redone = 0;
+    uint64_t est_sig = 0, bank_gen = 0, bank_hash = 0, counters_redone = 0;
     float scan_thr = 0.f, post_anchor = 0.f;
     int scan_mode = 0;
     int32_t post_overlap = 0;

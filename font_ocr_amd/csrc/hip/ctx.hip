@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -10,6 +11,15 @@ namespace focr {
 
 static std::mutex g_err_mu;
 static std::string g_err;
+
+// Size estimates shared between the contexts of a process (ctx.hip: focr_scan, finish_results), keyed by the setup's signature
+// (bank content, device, geometry, threshold, cap, mode): bounds only — a count above its bound redoes the batch exactly.
+struct SharedEstimate {
+    size_t cand, hits;
+    uint32_t row_max, seg_shift;
+};
+static std::mutex g_est_mu;
+static std::unordered_map<uint64_t, SharedEstimate> g_est;
 
 void set_global_error(const std::string &s) {
     std::lock_guard<std::mutex> lk(g_err_mu);
@@ -352,6 +362,20 @@ int focr_bank_upload(focr_ctx_t *c, const focr_template_t *templates, size_t n_t
     c->scanned = c->processed = false;
     c->sizes_pending = c->post_pending = false;
     c->bank_gen++;
+    {  // content id of the bank (FNV-1a over the records and the pixels): contexts that hold the same bank share their size estimates
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) {
+            const uint8_t *b = (const uint8_t *)p;
+            for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+        };
+        for (size_t t = 0; t < n_templates; t++) {
+            const focr_template_t &d = templates[t];
+            const uint32_t rec[3] = {d.letter, (uint32_t)d.n_w << 16 | d.n_h, d.offset};
+            mix(rec, sizeof rec);
+        }
+        mix(needles, needles_len);
+        c->bank_hash = h ^ (uint64_t)c->column_drop;
+    }
     std::vector<uint32_t> direct;
     std::vector<uint8_t> dense;
     bank_host_prepare(c, templates, n_templates, needles, direct, dense);
@@ -849,6 +873,11 @@ int finish_results(focr_ctx *c) {
                 c->row_seg_shift = sh;
                 if (c->h_res[5] > 2048 && sh > 5) c->row_seg_shift = sh - 1;
             }
+            if (c->est_sig) {  // for the other contexts that scan this setup (focr_scan): this batch's counts + the widest margin
+                std::lock_guard<std::mutex> lk(g_est_mu);
+                if (g_est.size() > 256) g_est.clear();
+                g_est[c->est_sig] = SharedEstimate{(size_t)n_cand + (size_t)n_cand / 5 + 8192, (size_t)n_hits + (size_t)n_hits / 5 + 8192, c->est_row_max, c->row_seg_shift};
+            }
         }
         c->counters[1] = n_hits;
         c->n_hits = c->n_hits_raw = (size_t)n_hits;
@@ -899,7 +928,7 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
     uint32_t tb;
     memcpy(&tb, &threshold, 4);
     uint64_t sig = 1469598103934665603ull;
-    for (uint64_t v : {(uint64_t)c->bank_gen, (uint64_t)c->n_pages, (uint64_t)c->r_w, (uint64_t)c->r_h, (uint64_t)tb, (uint64_t)cap, (uint64_t)mode,
+    for (uint64_t v : {(uint64_t)c->bank_hash, (uint64_t)c->device, (uint64_t)c->tail_mode, (uint64_t)c->n_pages, (uint64_t)c->r_w, (uint64_t)c->r_h, (uint64_t)tb, (uint64_t)cap, (uint64_t)mode,
                        (uint64_t)c->prefilter})
         sig = (sig ^ v) * 1099511628211ull;
     if (sig != c->est_sig) {
@@ -910,6 +939,19 @@ int focr_scan(focr_ctx_t *c, float threshold, uint32_t cap, int mode) {
         c->est_last_cand = c->est_last_hits = 0;
     }
     c->est_sig = sig;
+    if (c->est_cand == 0 && c->estimates_enabled && mode == FOCR_SCAN_MFMA) {
+        // no estimate of its own yet: another context of this process may have scanned the same setup (an executor's contexts take
+        // consecutive batches of one stream: only the stream's very first batch pays the exact-size scan with its host waits)
+        std::lock_guard<std::mutex> lk(g_est_mu);
+        auto it = g_est.find(sig);
+        if (it != g_est.end()) {
+            c->est_cand = it->second.cand;
+            c->est_hits = it->second.hits;
+            c->est_row_max = it->second.row_max;
+            c->row_seg_shift = it->second.seg_shift;
+            c->est_var = 0.0667;  // a neighbour's batch, not this context's: the widest margin was applied when it was published
+        }
+    }
     c->estimated = c->estimates_enabled && mode == FOCR_SCAN_MFMA && !c->force_split && c->est_cand != 0;
     return scan_now(c);
 }

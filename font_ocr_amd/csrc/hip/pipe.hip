@@ -317,15 +317,33 @@ int focr_pipe_create2(int device, unsigned n_lanes, unsigned depth, focr_pipe_t 
         focr_pipe_destroy(p);
         return rc;
     };
-    for (unsigned i = 0; i < n_lanes * depth; i++) {
-        PipeSlot *S = new PipeSlot();
-        S->lane = i % n_lanes;
-        int rc = focr_ctx_create(device, &S->ctx);
-        if (rc != FOCR_OK) {
-            delete S;
-            return bail(rc);
+    // the contexts side by side (a context is a stream, events, a few device and page-locked allocations: ~8 ms each, and an
+    // executor has six of them in front of its first batch)
+    {
+        (void)hipSetDevice(device);
+        (void)hipFree(nullptr);  // the runtime comes up once, here, not in six threads at the same time
+        std::vector<focr_ctx *> made(n_lanes * depth, nullptr);
+        std::vector<int> rcs(n_lanes * depth, FOCR_OK);
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < n_lanes * depth; i++) th.emplace_back([&, i] { rcs[i] = focr_ctx_create(device, &made[i]); });
+        for (std::thread &t : th) t.join();
+        int bad = FOCR_OK;
+        for (unsigned i = 0; i < n_lanes * depth; i++)
+            if (rcs[i] != FOCR_OK) bad = rcs[i];
+        for (unsigned i = 0; i < n_lanes * depth; i++) {
+            if (bad != FOCR_OK) {
+                if (made[i]) focr_ctx_destroy(made[i]);
+                continue;
+            }
+            PipeSlot *S = new PipeSlot();
+            S->lane = i % n_lanes;
+            S->ctx = made[i];
+            p->slots.push_back(S);
         }
-        p->slots.push_back(S);
+        if (bad != FOCR_OK) return bail(bad);
+    }
+    for (unsigned i = 0; i < n_lanes * depth; i++) {
+        PipeSlot *S = p->slots[i];
         if (i < n_lanes) {  // the lane: its stream is the first context's; a copy stream and a side stream of its own
             PipeLane *L = new PipeLane();
             L->stream = S->ctx->stream;
@@ -416,14 +434,18 @@ focr_ctx_t *focr_pipe_context(focr_pipe_t *p, unsigned index) { return (p && ind
 int focr_pipe_bank_upload(focr_pipe_t *p, const focr_template_t *templates, size_t n_templates, const uint8_t *needles, size_t needles_len) {
     if (!p) return fail(nullptr, FOCR_ERR_INVALID, "focr_pipe_bank_upload: null pipe");
     for (PipeSlot *S : p->slots) {
-        {
-            std::unique_lock<std::mutex> lk(p->mu);
-            p->cv.wait(lk, [&] { return S->state != PipeSlot::QUEUED && S->state != PipeSlot::TAKEN; });
-            if (S->state == PipeSlot::ENQUEUED) (void)complete(p, S, S->ticket, lk);  // a batch still in flight finishes with the old bank
-        }
-        int rc = focr_bank_upload(S->ctx, templates, n_templates, needles, needles_len);
-        if (rc != FOCR_OK) return rc;
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv.wait(lk, [&] { return S->state != PipeSlot::QUEUED && S->state != PipeSlot::TAKEN; });
+        if (S->state == PipeSlot::ENQUEUED) (void)complete(p, S, S->ticket, lk);  // a batch still in flight finishes with the old bank
     }
+    // every context prepares and uploads its own copy (host-side quantisation + a dozen small copies each): side by side
+    std::vector<int> rcs(p->slots.size(), FOCR_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < p->slots.size(); i++)
+        th.emplace_back([&, i] { rcs[i] = focr_bank_upload(p->slots[i]->ctx, templates, n_templates, needles, needles_len); });
+    for (std::thread &t : th) t.join();
+    for (size_t i = 0; i < rcs.size(); i++)
+        if (rcs[i] != FOCR_OK) return fail(nullptr, rcs[i], std::string("focr_pipe_bank_upload: ") + focr_last_error(p->slots[i]->ctx));
     return FOCR_OK;
 }
 

@@ -56,16 +56,22 @@ def main():
             (save_pgm if a.fmt == "pgm" else save_png)(path, pg)
     cmd = [NCC, "-f", FONT, "-t", "13", "--x-bits", "2", "-a", ASCII95, "-i"] + paths
     os.environ.setdefault("FOCR_CLI_TIMING", "1")  # phase / pipeline summary on stderr without -v's per-template lines
-    best, out = None, None
+    # stdout goes to a FILE: a pipe into this script measures how fast Python drains 11 MB (0.1-0.25 s of the 0.45-0.66 s that rounds
+    # 3-5 reported), not how fast the binary writes them
+    sink = os.path.join(a.dir, "stdout.txt")
+    best, out, walls = None, None, []
     for _ in range(a.repeat):
-        t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        dt = time.perf_counter() - t0
+        with open(sink, "wb") as f_out:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, stdout=f_out, stderr=subprocess.PIPE, text=True)
+            dt = time.perf_counter() - t0
         if r.returncode != 0:
             print(r.stderr[-2000:], file=sys.stderr)
             sys.exit(1)
+        walls.append(round(dt, 4))
         if best is None or dt < best:
             best, out = dt, r
+    text = open(sink, encoding="utf-8").read()
     px = a.pages * 608 * 720
     # steady-state rate: the marginal cost of the second half of the pages (process start-up and HIP initialisation,
     # ~0.2 s, are paid once whatever the page count)
@@ -73,14 +79,15 @@ def main():
     if a.pages >= 256:
         for _ in range(a.repeat):
             t0 = time.perf_counter()
-            r = subprocess.run(cmd[: cmd.index("-i") + 1] + paths[: a.pages // 2], capture_output=True, text=True)
+            r = subprocess.run(cmd[: cmd.index("-i") + 1] + paths[: a.pages // 2], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
             dt = time.perf_counter() - t0
             if r.returncode == 0 and (half is None or dt < half):
                 half = dt
     marginal = (px / 2) / (best - half) / 1e6 if half and best > half else None
     print(json.dumps({"pages": a.pages, "fmt": a.fmt, "wall_s": round(best, 4), "pages_per_s": round(a.pages / best, 1),
                       "wall_s_half_the_pages": half and round(half, 4), "marginal_Mpx_per_s": marginal and round(marginal, 1),
-                      "Mpx_per_s": round(px / best / 1e6, 1), "chars": sum(len(l) for l in out.stdout.splitlines()),
+                      "Mpx_per_s": round(px / best / 1e6, 1), "wall_s_all_runs": walls, "chars": sum(len(l) for l in text.splitlines()),
+                      "stdout_sha16": __import__("hashlib").sha256(text.encode()).hexdigest()[:16],
                       "stderr_tail": out.stderr.strip().splitlines()[-14:]}))
 
 
