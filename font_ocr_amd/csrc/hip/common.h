@@ -301,6 +301,7 @@ void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layou
 int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s);  // ctx.hip
 int pages_alt_swap(focr_ctx *c, size_t n_pages, size_t r_w, size_t r_h);
 void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream);  // ctx.hip: the context joins an executor's lane
+bool post_queue_chars_copy(focr_ctx *c, void *dst, size_t dst_bytes);  // post.hip: the batch's characters to a device buffer, queued on the context's stream
 int wait_batch(focr_ctx *c);  // ctx.hip: until the context's queued work is done (its batch's event inside an executor, else its stream)
 int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of);  // host only
 

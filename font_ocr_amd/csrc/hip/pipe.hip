@@ -78,6 +78,7 @@ struct PipeSlot {
     PinBuf h_counts, h_page_off, h_line_off, h_chars;
     focr_host_results_t res{};
     bool fetched = false;
+    bool chars_queued = false;  // the copy into job.chars_out was queued behind process_hits on the lane's stream (no copy at completion)
     // focr_pipe_prefetch: the slot's NEXT batch crosses PCIe into the lane's staging buffer and is ingested into the context's
     // ALTERNATE page set (pages_alt_ingest, ctx.hip), both on the lane's copy stream, under the batches in flight; when the
     // announced batch is queued, the context's two page sets change places
@@ -210,6 +211,8 @@ static void enqueue_main(focr_pipe *P) {
         if (rc == FOCR_OK) rc = focr_scan(c, job.threshold, job.cap, job.mode);
         S->times.scan_queued_us = P->now_us();
         if (rc == FOCR_OK && job.post) rc = focr_process_hits(c, job.anchor_threshold, job.overlap);
+        // the characters' copy into the caller's device buffer rides on the lane's stream too (a kernel that reads their number on the device)
+        S->chars_queued = rc == FOCR_OK && job.post && job.chars_out && post_queue_chars_copy(c, job.chars_out, job.chars_cap);
         if (rc == FOCR_OK) {
             S->ev_done = P->done_ring[t % focr_pipe::DONE_RING];
             hipError_t e = hipEventRecord(S->ev_done, c->stream);
@@ -243,7 +246,9 @@ static int complete(focr_pipe *P, PipeSlot *S, uint64_t t, std::unique_lock<std:
     lk.unlock();
     focr_ctx *c = S->ctx;
     PipeLane *L = P->lanes[S->lane];
+    const uint64_t redone_before = c->counters_redone;
     if (rc == FOCR_OK) rc = focr_sync(c);  // the batch's event, then its sizes (a batch whose estimates were too small is redone here)
+    if (c->counters_redone != redone_before) S->chars_queued = false;  // ... and what was copied out behind its first attempt is void
     S->times.done_us = P->now_us();
     S->times.device_gap_ms = -1.f;
     if (rc == FOCR_OK && prev_ok) {
@@ -251,12 +256,12 @@ static int complete(focr_pipe *P, PipeSlot *S, uint64_t t, std::unique_lock<std:
         if (hipEventElapsedTime(&ms, prev_ev, S->ev_done) == hipSuccess) S->times.device_gap_ms = ms;
         else (void)hipGetLastError();  // the previous batch is still running (batches retired out of order): no interval
     }
-    if (rc == FOCR_OK && job.post && job.chars_out) {  // copy-out on the lane's side stream: the batch is complete, its own stream holds the next one
+    if (rc == FOCR_OK && job.post && job.chars_out) {
         const size_t bytes = focr_total_chars(c) * sizeof(focr_hit_t);
         if (bytes > job.chars_cap) {
             rc = fail(c, FOCR_ERR_OVERFLOW, "focr_pipe_submit: chars_out is too small for this batch");
-        } else if (bytes) {
-            hipError_t e = hipMemcpyAsync(job.chars_out, focr_lines_device_chars(c), bytes, hipMemcpyDeviceToDevice, L->io_stream);
+        } else if (bytes && !S->chars_queued) {  // (exact-size batches, a batch redone: the results were final before a copy could be queued) on the lane's side stream
+            hipError_t e = hipMemcpyAsync(job.chars_out, focr_lines_device_chars(c), bytes, hipMemcpyDefault, L->io_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(L->io_stream);
             if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: copy-out failed: ") + hipGetErrorString(e));
         }

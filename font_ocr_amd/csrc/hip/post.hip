@@ -163,6 +163,25 @@ __global__ void page_offsets(const uint64_t *__restrict__ scanned, uint32_t r_h,
     page_line_off[p] = scanned[(size_t)min(p, n_pages) * r_h] >> 32;  // p == n_pages: the scan's grand total
 }
 
+// the batch's characters to a caller's device buffer, queued behind process_hits on the context's stream: their number is still
+// on the device (the low word of the row scan's grand total), so the copy is a kernel that reads it there
+__global__ __launch_bounds__(256) void copy_chars_kernel(const uint32_t *__restrict__ src, const uint64_t *__restrict__ total, uint32_t *__restrict__ dst, uint64_t dst_dwords) {
+    constexpr uint64_t DW = sizeof(focr_hit_t) / 4;
+    const uint64_t n = min((*total & 0xffffffffull) * DW, dst_dwords);  // a buffer that is too small is reported when the batch is completed
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// Queue the copy of the last focr_process_hits' characters into dst (device memory, dst_bytes) on the context's stream; false if
+// there is nothing queued to copy from (no hits at all / results already final): the caller copies after completion instead.
+bool post_queue_chars_copy(focr_ctx *c, void *dst, size_t dst_bytes) {
+    static_assert(sizeof(focr_hit_t) % 4 == 0, "focr_hit_t is copied as dwords");
+    if (!c->post_pending || !c->post_scanned.p || !c->post_chars.p || !dst) return false;
+    const size_t n_rows_total = c->n_pages * c->r_h;
+    hipLaunchKernelGGL(copy_chars_kernel, dim3(64), dim3(256), 0, c->stream, (const uint32_t *)c->post_chars.p, (const uint64_t *)c->post_scanned.p + n_rows_total,
+                       (uint32_t *)dst, (uint64_t)(dst_bytes / 4));
+    return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace focr
 
 using namespace focr;

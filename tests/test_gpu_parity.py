@@ -860,6 +860,46 @@ def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
         pipe.close()
 
 
+def test_pipeline_chars_out_with_estimated_and_redone_batches(bank_x2):
+    """chars_out of focr_pipe_submit: the characters' copy into the caller's device buffer is queued behind process_hits on the lane's
+    stream (a kernel that reads their number on the device) — also when the batch runs on size estimates, and a batch whose estimates
+    prove too small is redone and copied again after the redo.  One lane, one context: every batch meets its predecessor's estimates."""
+    from font_ocr_amd.bank import HIT_DTYPE
+    from font_ocr_amd.searcher import PinnedPages, Pipeline
+
+    dense = synth_pages(bank_x2, 3, 400, 200, first=8800)
+    sparse = dense.copy()
+    sparse[:, 50:, :] = 255
+    want = {}
+    with Scanner(0) as sc:
+        sc.set_bank(bank_x2)
+        for name, pg in (("dense", dense), ("sparse", sparse)):
+            sc.set_pages(pg)
+            sc.scan(0.8, 1024, SCAN_DIRECT)
+            sc.process_hits(0.95, 5)
+            want[name] = sc.lines_flat().tobytes()
+    assert len(want["dense"]) > 3 * len(want["sparse"]) > 0
+    pipe = Pipeline(0, 1, 1)
+    try:
+        pipe.set_bank(bank_x2)
+        pin = PinnedPages(1, 1, 1 << 20)  # page-locked host memory is device-accessible: a device buffer as far as the executor is concerned
+        buf = pin.array.reshape(-1)
+        redone0 = pipe.scanners[0].size_estimate_stats()["redone"]
+        for name, pg in (("sparse", sparse), ("sparse", sparse), ("dense", dense), ("dense", dense), ("sparse", sparse)):
+            buf[:] = 0
+            t = pipe.submit(pg, 0.8, chars_out=(buf.ctypes.data, buf.size))
+            sc = pipe.wait(t)
+            n = sc.total_chars() * HIT_DTYPE.itemsize
+            assert n == len(want[name])
+            got = buf[:n].tobytes()
+            pipe.release(t)
+            assert got == want[name], name
+        assert pipe.scanners[0].size_estimate_stats()["redone"] >= redone0 + 1  # sparse -> dense: the bound was too small
+    finally:
+        pipe.close()
+        pin.close()
+
+
 def test_pipeline_prefetch_matches_oracle(bank_x2):
     """Round 4: batches announced ahead with focr_pipe_prefetch (their DMA and ingest run on a copy stream, into the lane's alternate
     page set, while the lane still works on its previous batch) — same lists as the oracle, announcements must be submitted in order,
