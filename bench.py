@@ -381,6 +381,9 @@ def main():
         if args.legacy_tail:
             args.tail = "legacy"
         c_.set_row_tail({"hits": 1, "legacy": 0}[args.tail])
+        if os.environ.get("FOCR_BENCH_TAIL_GRID"):  # experiments: the tail's persistent kernels on num/den times their workgroups (focr_debug_set_tail_grid)
+            num_, den_ = os.environ["FOCR_BENCH_TAIL_GRID"].split("/")
+            c_.set_tail_grid(int(num_), int(den_))
     pipe.set_bank(bank)
     scs, pages = [], None
     shard = None  # --config c4: the rank's contiguous block of the page set, resident in HBM

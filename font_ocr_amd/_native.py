@@ -124,8 +124,8 @@ HIP_SYMBOLS = {
     "focr_size_estimate_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "focr_ctx_set_column_drop": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_ctx_set_row_tail": (C.c_int, [C.c_void_p, C.c_int]),
-    "focr_debug_f16_down": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
-    "focr_debug_f16_down_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "focr_debug_plane_value": (None, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "focr_debug_plane_value_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "focr_debug_prefilter": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "focr_pipe_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),

@@ -166,7 +166,7 @@ struct focr_ctx {
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
     uint32_t dbg_grid_num = 0, dbg_grid_den = 0;  // tests: the tail's persistent kernels on num / den times their workgroups (focr_debug_set_tail_grid; 0: as designed)
     int prefilter = 0;                          // FOCR_PREFILTER_*: auto / plane kernel / legacy kernel (focr_ctx_set_prefilter)
-    uint16_t *d_planes = nullptr;               // threshold planes, f16: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
+    uint16_t *d_planes = nullptr;               // threshold planes, int16: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)
     size_t planes_bytes = 0;
     uint32_t *d_tglobal = nullptr;              // class-ordered -> global template index, 0xffffffff = never emits
     uint32_t *d_order_of = nullptr;             // global template index -> class-ordered index

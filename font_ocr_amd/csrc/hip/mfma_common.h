@@ -34,7 +34,7 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
 
 // ---- threshold planes ------------------------------------------------------------------------
 // The statistics kernel turns every window of a size class into ONE number, the prefilter threshold L of that window, and
-// stores it as f16 in units of a per-class power of two S ("threshold plane", 2 B per window and class):
+// stores it as a 16-bit integer in units of a per-class power of two S ("threshold plane", 2 B per window and class):
 //
 //     L(w) = kappa * norm_p(w)  -  c * rho_max * dnorm(w)            candidate  <=>  G(w, t) > L(w)
 //
@@ -51,52 +51,23 @@ __device__ __forceinline__ void flush_wave_candidates(uint64_t *wbuf, uint32_t c
 //     W = n_k^2*q2 - 2*n_k*s_k*q1 + D*s_k^2 = n_k^2 * dnorm^2        (q1, q2: sums over the dropped column, D its taps;
 //                                                                      evaluated as an f32 upper bound: dropped_column_W_upper)
 // then L = kq*sqrt(V) - crk*sqrt(W) in f32 with kq rounded towards -inf and crk up (host: plane_params) — f32 errors stay
-// below 1 for |L| < 4e6 and are absorbed by a "- 2" — and the stored value is (L - 2) / S rounded TOWARDS -INF
-// to f16 (a lower threshold only admits more candidates), +inf where the reference never emits (x = 0, y = 0, window outside
-// the page, zero variance).  Round 2 stored the window norm (rounded towards zero) and multiplied by kappa in the scan
-// kernel, which raised the threshold for kappa < 0; a directed rounding of L itself has no sign cases.
+// below 1 for |L| < 4e6 and are absorbed by a "- 2" — and the stored value is the C-in itself in units of S:
+//     nq = -floor((L - 2) / S)  as int16,     C-in = nq * S = nq << log2(S),     D = G + C-in > 0  <=>  G > floor((L - 2) / S) * S
+// a threshold rounded TOWARDS -INF (a lower threshold only admits more candidates), whatever the signs; -32768 where the reference
+// never emits (x = 0, y = 0, window outside the page, zero variance): S >= K / 2 for K bytes per window (plane_params), so that
+// 32768 * S exceeds every |G| <= K * 127 * 128 — the pair never passes.  Round 2 stored the window norm (rounded towards zero)
+// and multiplied by kappa in the scan kernel, which raised the threshold for kappa < 0; rounds 3-4 stored L as f16 rounded
+// towards -inf (the same directed rounding, but five vector instructions per window and class in the scan kernel's item prologue
+// to turn it into an integer: convert, multiply, floor, clamp, convert).  The integer plane needs ONE (a shift): S = 64 at
+// BASELINE configs[1], i.e. thresholds of 1e5 .. 6e5 in steps of 64 — as fine as f16's 11 bits there.
 struct PlaneParams {
-    float kq;     // kappa / sqrt(n), towards -inf
-    float crk;    // c * rho_max * (1 + 1e-4) / n_keep, upwards (0: nothing dropped)
-    float S;      // power of two: |L| / S < 32768 for every window
-    float inv_S;  // 1 / S (exact)
+    float kq;        // kappa / sqrt(n), towards -inf
+    float crk;       // c * rho_max * (1 + 1e-4) / n_keep, upwards (0: nothing dropped)
+    float S;         // power of two, >= K / 2: |L - 2| / S <= 16384 for every window whose |L| is below 2^28
+    float inv_S;     // 1 / S (exact)
+    uint32_t shift;  // log2(S), 5 .. 14
 };
-
-// f32 -> f16 bits, rounded towards -inf (|x| < 65504)
-__host__ __device__ inline uint16_t f16_down(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x, 0.f);  // towards zero
-    uint32_t h = __builtin_bit_cast(uint32_t, h2) & 0xffffu;
-    const float back = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
-    if (back > x) h += 1;  // only negative x: one step away from zero (-0 -> the smallest negative subnormal)
-    return (uint16_t)h;
-#else
-    const uint32_t u = __builtin_bit_cast(uint32_t, x), sign = u >> 31, a = u & 0x7fffffffu;
-    uint32_t h;
-    bool inexact;
-    if (a == 0x7f800000u) {  // +-inf stays +-inf
-        h = 0x7c00;
-        inexact = false;
-    } else if (a >= 0x47800000u) {  // |x| >= 65536: the largest finite f16 towards -inf from above, -inf from below (NaN: callers never pass one)
-        h = 0x7bff;
-        inexact = true;
-    } else if (a >= 0x38800000u) {  // normal f16
-        h = (a - 0x38000000u) >> 13;
-        inexact = (a & 0x1fffu) != 0;
-    } else if (a >= 0x33000000u) {  // subnormal f16: value = h * 2^-24
-        const uint32_t e = a >> 23, m = (a & 0x7fffffu) | 0x800000u, shift = 126 - e;
-        h = m >> shift;
-        inexact = (m & ((1u << shift) - 1)) != 0;
-    } else {
-        h = 0;
-        inexact = a != 0;
-    }
-    if (sign && inexact) h += 1;
-    return (uint16_t)(h | (sign << 15));
-#endif
-}
-__host__ __device__ inline float f16_bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-constexpr uint16_t PLANE_NEVER = 0x7c00;  // +inf: the reference never emits at this window
+constexpr int16_t PLANE_NEVER = -32768;  // the reference never emits at this window: an unreachable threshold
 
 // f32 square root: the raw 1-ulp instruction on the device, the correctly rounded one in the host model
 __host__ __device__ inline float sqrt_fast(float x) {
@@ -127,36 +98,18 @@ __host__ __device__ inline int32_t threshold_negL(float Lf) {
     f = __builtin_fminf(__builtin_fmaxf(f, -1.0e9f), 1.0e9f);
     return -(int32_t)f;
 }
-// Plane value of a window that can emit: (L - 2) / S rounded towards -inf to f16 — the "- 2" that absorbs the f32 roundings
-// of L rides in the stored value, so the scan kernel's C-in costs it one instruction less per window and size class.
-// No clamp on the way (round 4): S covers every |L| the host bounds (plane_params), and beyond that — a --threshold of +-1e30 —
-// the directed rounding does the right thing by itself: above the f16 range a positive value becomes the largest finite f16
-// (a threshold still far above any |G| < 2^24 / ... the pair never passes), a negative one -inf, which prefilter_cin turns into
-// "every pair passes"; both are lower than the true threshold, i.e. conservative.
-__host__ __device__ inline uint16_t plane_value(const PlaneParams &p, float Lf) { return f16_down((Lf - 2.0f) * p.inv_S); }
-// The same inside a kernel that has switched the f16 / f64 rounding mode of its waves to "towards -inf" (f16_round_down_mode():
-// MODE.FP_ROUND[3:2] = 2; f32 arithmetic has its own two bits and stays at nearest-even): the conversion is ONE instruction
-// instead of convert-towards-zero, convert back, compare, add.  Bit-equal to f16_down for every float, subnormals and the
-// overflows above included (tests/test_gpu_parity.py::test_threshold_plane_rounding_device_equals_host runs both device forms).
-__device__ __forceinline__ void f16_round_down_mode() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | ((2 - 1) << 11), 2);
-#endif
+// Plane value of a window that can emit: nq = -floor((L - 2) / S), clamped to +-32767 (beyond that — a --threshold of +-1e30 —
+// the clamp does the right thing by itself: a threshold above 32767 * S is unreachable either way, one below -32767 * S passes
+// every pair either way; NaN cannot occur: kq and crk are finite, V and W finite and >= 0).  The same arithmetic on the host
+// (the model) and on the device (exact scaling by a power of two, floor, an exact conversion): bit-identical by construction,
+// checked by tests/test_gpu_parity.py::test_threshold_plane_values_device_equals_host.
+__host__ __device__ inline int16_t plane_value(const PlaneParams &p, float Lf) {
+    float t = __builtin_floorf((Lf - 2.0f) * p.inv_S);
+    t = __builtin_fminf(__builtin_fmaxf(t, -32767.0f), 32767.0f);
+    return (int16_t)(-(int)t);
 }
-__device__ __forceinline__ uint16_t f16_down_mode(float x) {
-    uint32_t h = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_cvt_f16_f32_e32 %0, %1" : "=v"(h) : "v"(x));
-#endif
-    return (uint16_t)h;
-}
-__device__ __forceinline__ uint16_t plane_value_mode(const PlaneParams &p, float Lf) { return f16_down_mode((Lf - 2.0f) * p.inv_S); }
-// C-in of one window from its plane value v (as f32; +inf = never): -floor(S * v).  S * v is exact (S a power of two);
-// +inf comes out as -1e9, an unreachable threshold (|G| < 2^24).  Five instructions: cvt, mul, floor, med3, cvt (negated).
-__host__ __device__ inline int prefilter_cin(float S, float v) {
-    const float f = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(S * v), -1.0e9f), 1.0e9f);
-    return -(int)f;
-}
+// C-in of one window from its plane value: nq * S (|C-in| <= 2^29: G + C-in cannot wrap).  One shift.
+__host__ __device__ inline int prefilter_cin(uint32_t shift, int16_t nq) { return (int)((uint32_t)(int)nq << shift); }
 
 // How the waves of a persistent scan kernel get their work.  Items (MT consecutive live M-tiles) are split into one
 // contiguous range per XCD: workgroups b and b + 8 share an XCD and its L2, and neighbouring M-tiles share page rows.  Inside
@@ -449,10 +402,10 @@ __device__ __forceinline__ bool verify_candidate(uint64_t key, const VerifyArgs 
 // Per-launch description of the threshold planes of the pass's size classes (scan_mfma2s_kernel).
 constexpr int MAX_PLANE_VALUES = 4;  // size classes per pass on the plane path (the kernel is instantiated for 1 / 2 / 4)
 struct PlaneArgs {
-    const uint16_t *planes;  // f16 bits: value 0 of the sub-batch's first page; values are `stride` elements apart
+    const uint16_t *planes;  // int16 plane values (nq): value 0 of the sub-batch's first page; values are `stride` elements apart
     size_t stride;
     uint32_t nv;
-    float S[MAX_SEGS];             // per segment of the launch: the unit of its class's plane
+    uint32_t shift[MAX_SEGS];      // per segment of the launch: log2 of the unit of its class's plane
     uint32_t seg_value[MAX_SEGS];  // per segment: the plane (value) of its class
     uint32_t seg_full[MAX_SEGS];   // per segment: 0 if the class's templates are all zero in the last K-step (LAYOUT_W12, kept width <= 8)
     uint32_t seg_dead_from[MAX_SEGS];  // per segment: first N-tile (chunk-local) that holds dead / padding slots — a class's live templates come first

@@ -2,7 +2,7 @@
 //
 // No device call: the quantised bank is built by the very function focr_bank_upload uses (quantise_bank), the threshold of a
 // window by the very inline functions the statistics and scan kernels use (mfma_common.h: dropped_column_W, threshold_f32,
-// f16_down, prefilter_cin).  The CPU tests check the property the whole fast path rests on — the reference emits
+// plane_value, prefilter_cin).  The CPU tests check the property the whole fast path rests on — the reference emits
 // (sim > thr)  =>  the prefilter flags the pair (G + C-in > 0) — on text, noise, degenerate and adversarial windows, for
 // positive and negative thresholds, with and without the column drop (tests/test_prefilter_host.py).
 #include <cmath>
@@ -70,8 +70,8 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
             const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;
             const float Wf = kw != sc.n_w ? dropped_column_W_upper(n_k, n - n_k, s - q1, q1, q2) : 0.f;
             const float Lf = threshold_f32(p, (float)V, Wf);
-            const uint16_t plane = V != 0 ? plane_value(p, Lf) : PLANE_NEVER;
-            const int cin = prefilter_cin(p.S, f16_bits_to_f32(plane));
+            const int16_t plane = V != 0 ? plane_value(p, Lf) : PLANE_NEVER;
+            const int cin = prefilter_cin(p.shift, plane);
             const double norm_p = std::sqrt((double)V / (double)n);
             for (uint32_t i = 0; i < sc.n_templates; i++) {
                 const TemplateConst &tc = c->h_tconst[sc.first + i];
@@ -97,31 +97,35 @@ extern "C" int focr_debug_prefilter(const focr_template_t *templates, size_t n_t
     return FOCR_OK;
 }
 
-// the plane's directed rounding, host flavour (the device flavour is checked against it on the GPU: test_gpu_parity.py)
-extern "C" void focr_debug_f16_down(const float *x, size_t n, uint16_t *out) {
-    for (size_t i = 0; i < n; i++) out[i] = f16_down(x[i]);
+// the plane value of a threshold L for a unit 2^shift (mfma_common.h: plane_value), host flavour (the device's is checked against it
+// on the GPU: test_gpu_parity.py)
+extern "C" void focr_debug_plane_value(const float *L, size_t n, uint32_t shift, int16_t *out) {
+    PlaneParams p{};
+    p.shift = shift;
+    p.S = std::ldexp(1.0f, (int)shift);
+    p.inv_S = std::ldexp(1.0f, -(int)shift);
+    for (size_t i = 0; i < n; i++) out[i] = plane_value(p, L[i]);
 }
 
-// ... and the device flavour (v_cvt_pkrtz + fix-up), for the GPU test that compares the two bit for bit
-__global__ void f16_down_kernel(const float *__restrict__ x, size_t n, uint16_t *__restrict__ out, int mode_form) {
+// ... and the device flavour, for the GPU test that compares the two bit for bit
+__global__ void plane_value_kernel(const float *__restrict__ x, size_t n, PlaneParams p, int16_t *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (mode_form) {  // the statistics kernel's form: the wave's f16 rounding mode set to "towards -inf", one conversion instruction
-        f16_round_down_mode();
-        if (i < n) out[i] = f16_down_mode(x[i]);
-    } else if (i < n) {
-        out[i] = f16_down(x[i]);
-    }
+    if (i < n) out[i] = plane_value(p, x[i]);
 }
-extern "C" int focr_debug_f16_down_device(focr_ctx_t *c, const float *x, size_t n, uint16_t *out, int mode_form) {
-    if (!c || !x || !out || !n) return fail(c, FOCR_ERR_INVALID, "focr_debug_f16_down_device: bad arguments");
+extern "C" int focr_debug_plane_value_device(focr_ctx_t *c, const float *x, size_t n, uint32_t shift, int16_t *out) {
+    if (!c || !x || !out || !n) return fail(c, FOCR_ERR_INVALID, "focr_debug_plane_value_device: bad arguments");
     FOCR_HIP(c, hipSetDevice(c->device));
+    PlaneParams p{};
+    p.shift = shift;
+    p.S = std::ldexp(1.0f, (int)shift);
+    p.inv_S = std::ldexp(1.0f, -(int)shift);
     float *dx = nullptr;
-    uint16_t *dout = nullptr;
+    int16_t *dout = nullptr;
     auto run = [&]() -> int {
         FOCR_HIP(c, hipMalloc((void **)&dx, n * 4));
         FOCR_HIP(c, hipMalloc((void **)&dout, n * 2));
         FOCR_HIP(c, hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(f16_down_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx, n, dout, mode_form);
+        hipLaunchKernelGGL(plane_value_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx, n, p, dout);
         FOCR_HIP(c, hipGetLastError());
         FOCR_HIP(c, hipMemcpyAsync(out, dout, n * 2, hipMemcpyDeviceToHost, c->stream));
         FOCR_HIP(c, hipStreamSynchronize(c->stream));

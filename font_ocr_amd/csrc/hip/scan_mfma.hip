@@ -6,9 +6,9 @@
 //
 //  1. window statistics (stats_kernel): per size class and window, the exact integer sums s_p, s2_p, V = n*s2 - s^2 (V > 0 <=> the
 //     reference's rnorm is finite, src/ncc.rs:309-311) and — for a class whose last column the MFMA does not multiply — that
-//     column's sums.  From them the window's prefilter THRESHOLD L(w) in f32 (mfma_common.h, "threshold planes"), stored as f16
-//     in units of a per-class power of two and rounded TOWARDS -INF ("threshold plane", 2 B per window and class); +inf where the
-//     reference never emits (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN).  A lower threshold only admits more
+//     column's sums.  From them the window's prefilter THRESHOLD L(w) in f32 (mfma_common.h, "threshold planes"), stored as the
+//     MFMA's C-in in units of a per-class power of two, rounded TOWARDS -INF as a threshold ("threshold plane", an int16 per window
+//     and class); the most negative value where the reference never emits (x = 0, y = 0, out of range, zero variance => rnorm = inf/NaN).  A lower threshold only admits more
 //     candidates, so the directed rounding has no sign cases: the filter is conservative for negative --threshold too (round 2
 //     stored the window norm rounded towards zero and multiplied by kappa in the scan kernel, which RAISED the threshold for
 //     kappa < 0).  (Legacy form, still used for size classes with more than 4 K-steps: negL(w) = -(floor(L) - 2) as int32, or
@@ -16,7 +16,7 @@
 //  2. MFMA prefilter (scan_mfma2.hip): every template is mean-centred, scaled by a class-wide constant c/norm_n(t) and rounded
 //     to int8 with the rounding chosen so that sum_k bq_k = 0.  G(w,t) = sum_k (a_k - 128) bq_k  (= sum_k a_k bq_k) is one
 //     v_mfma_i32_16x16x64_i8 chain over the window's bytes (16 templates x 16 windows, K = 64 bytes per instruction) with
-//     C-in = -floor(S * plane value), so "D > 0" <=> G > L(w).  Cauchy-Schwarz bounds the rounding error:
+//     C-in = plane value << log2(S), so "D > 0" <=> G > L(w) rounded down to a multiple of S.  Cauchy-Schwarz bounds the rounding error:
 //         | c*num/norm_n - G | = | sum_k (a_k - mean_w) e_k | <= norm_p * ||e_t||_2
 //     hence sim > thr  ==>  G > (c*thr - max_t ||e_t||) * norm_p =: kappa * norm_p; kappa carries an extra relative margin for
 //     the f64 roundings of the exact formula.  Classes 9 or 13 px wide leave their last column to a second Cauchy-Schwarz term,
@@ -95,17 +95,17 @@ static inline size_t stats_lds_bytes(uint32_t n_h) { return (size_t)(STY + n_h -
 
 struct StatsOut {  // what a statistics launch writes for one size class
     PlaneParams p;
-    void *out;     // OUT = 1: f16 threshold plane, OUT = 0: int32 negL table; [page][Lrows][Lpitch]
+    void *out;     // OUT = 1: int16 threshold plane, OUT = 0: int32 negL table; [page][Lrows][Lpitch]
 };
 
 // IDX: uint32_t on the plane path (a pass's planes span < 4 GiB: launch_scan_mfma), size_t for the int32 tables
 template <int OUT, typename IDX>
 __device__ __forceinline__ void stats_store(const StatsOut &o, IDX idx, bool emit, float Lf) {
     if (OUT) {
-        // the kernel runs in the "f16 conversions round towards -inf" mode (f16_round_down_mode); a pass's planes span < 4 GiB
-        // (launch_scan_mfma), so the entry's BYTE offset fits 32 bits: uniform base + 32-bit lane offset, no 64-bit vector add per store
+        // a pass's planes span < 4 GiB (launch_scan_mfma), so the entry's BYTE offset fits 32 bits: uniform base + 32-bit lane offset,
+        // no 64-bit vector add per store
         const uint32_t byte_off = (uint32_t)idx * 2u;
-        *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(o.out) + byte_off) = emit ? plane_value_mode(o.p, Lf) : PLANE_NEVER;
+        *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(o.out) + byte_off) = emit ? plane_value(o.p, Lf) : PLANE_NEVER;
     } else {
         reinterpret_cast<int32_t *>(o.out)[idx] = emit ? threshold_negL(Lf) : -REJECT;
     }
@@ -119,7 +119,6 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     // dynamic LDS, sized for this class's n_h (stats_lds_bytes): ~21 KB at n_h = 15 -> 7 blocks per CU; the kernel
     // lives on that occupancy (global-load latency, two barriers per tile)
     extern __shared__ uint32_t stats_lds[];
-    if (OUT) f16_round_down_mode();  // plane values are converted with one instruction each (mfma_common.h)
     const uint32_t page = blockIdx.z, x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const uint32_t rows = STY + n_h - 1;
     uint32_t (*tile)[SLDW] = reinterpret_cast<uint32_t (*)[SLDW]>(stats_lds);
@@ -582,12 +581,17 @@ PlaneParams plane_params(const focr_ctx *c, size_t k, double thr_d) {
         if ((double)cr < cr_d) cr = std::nextafterf(cr, INFINITY);
         p.crk = std::nextafterf(std::nextafterf(cr, INFINITY), INFINITY);  // also covers a 1-ulp-low square root of W
     }
-    // |L| <= |kq| * sqrt(V) + crk * sqrt(W) with sqrt(V) <= 127.5 n, sqrt(W) <= 255 n_k sqrt(D); the kernel clamps L to +-1e9
-    const double l_max = std::min(1.0e9, std::fabs((double)p.kq) * 127.5 * n + (double)p.crk * 255.0 * n_k * std::sqrt(std::max(D, 0.0)));
-    int e = 0;
-    std::frexp(std::max(l_max / 32768.0, std::ldexp(1.0, -20)), &e);  // value = m * 2^e, m in [0.5, 1): 2^e >= value
-    p.S = std::ldexp(1.0f, e);
-    p.inv_S = std::ldexp(1.0f, -e);
+    // |L| <= |kq| * sqrt(V) + crk * sqrt(W) with sqrt(V) <= 127.5 n, sqrt(W) <= 255 n_k sqrt(D).  The plane's unit S, a power of two
+    // (mfma_common.h): every |L - 2| / S within 16384 while |L| < 2^28 (beyond that the plane value's clamp takes over: such
+    // thresholds are unreachable or pass everything either way), and S >= K / 2 for the K bytes the MFMA multiplies per window, so
+    // that the "never" value -32768 * S lies below every -|G| (|G| <= K * 127 * 128).  S <= 2^14: |C-in| <= 2^29, G + C-in cannot wrap.
+    const double l_max = std::min(std::ldexp(1.0, 28), std::fabs((double)p.kq) * 127.5 * n + (double)p.crk * 255.0 * n_k * std::sqrt(std::max(D, 0.0)) + 4.0);
+    const double s_min = std::max(l_max / 16384.0, 16.0 * (double)std::max<uint32_t>(sc.k_groups, 4) / 2.0);  // K = 16 bytes per k-group
+    uint32_t e = 5;
+    while (std::ldexp(1.0, (int)e) < s_min && e < 14) e++;
+    p.shift = e;
+    p.S = std::ldexp(1.0f, (int)e);
+    p.inv_S = std::ldexp(1.0f, -(int)e);
     return p;
 }
 
@@ -724,12 +728,12 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         if (!clear.add(live, tiles_total + 16)) return fail(c, FOCR_ERR_INVALID, "scan_mfma: clear list full or region too large");
         if ((rc = launch_clear(c, clear))) return rc;
         // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
-        const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // f16 values per plane
+        const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // int16 values per plane
         std::vector<int> two(c->supers.size(), 0);
         std::vector<size_t> plane_off(c->supers.size(), 0);
         size_t plane_vals = 0;
         // two[si]: 0 = legacy path (per-class int32 negL tables, scan_mfma2_kernel: > 4 K-steps or > 4 size classes),
-        //          1 = f16 threshold planes + scan_mfma2s_kernel (A = templates, B = windows)
+        //          1 = int16 threshold planes + scan_mfma2s_kernel (A = templates, B = windows)
         for (size_t si = 0; si < c->supers.size(); si++) {
             const SuperClass &su = c->supers[si];
             if (!su.mtx || su.ksteps > 4 || su.classes.size() > (size_t)MAX_PLANE_VALUES || c->prefilter == FOCR_PREFILTER_LEGACY) continue;
@@ -834,7 +838,7 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                         }
                         break;
                     }
-                    A3.S[L.segs.n] = plane_params(c, su.classes[i], thr_d).S;  // the unit of the class's plane
+                    A3.shift[L.segs.n] = plane_params(c, su.classes[i], thr_d).shift;  // the unit of the class's plane
                     A3.seg_value[L.segs.n] = (uint32_t)i;
                     A3.seg_full[L.segs.n] = (su.layout == LAYOUT_W12 && sc.keep_w <= 8) ? 0u : 1u;  // mfma_common.h: K layouts
                     {  // tiles of the class from n_live / 16 on hold dead / padding slots; chunk-local numbering

@@ -7,7 +7,7 @@
 // per workgroup, so a kernel has exactly one barrier; there is no per-tile fill/drain.  One workgroup per CU.
 //
 //   scan_mfma2s_kernel  the default (<= 4 K-steps, <= 4 size classes per pass): A = templates, B = windows, the C-in of a
-//                       lane is the threshold of its own window, formed in registers from the f16 threshold planes; 16
+//                       lane is the threshold of its own window, one shift away from its int16 threshold-plane value; 16
 //                       waves x 4 M-tiles per CU, 128 VGPRs.
 //   scan_mfma2_kernel   round 1's form (A = windows, int32 negL rows re-loaded per size class), kept for 5..8 K-steps and
 //                       as a cross-check (FOCR_PREFILTER_LEGACY); 8 waves x 4..8 M-tiles for the long layouts.
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void scan_mfma2_kernel(
 // ---------------------------------------------------------------------------------------------
 // The same one-stage prefilter with the operand roles swapped: (A = templates, B = windows), so D[template][window] puts
 // window px + r on lane (r, g) for all four accumulator registers.  The C-in of a lane is then the threshold of its OWN
-// window: one f16 threshold-plane value per size class and M-tile (mfma_common.h) stays in a register for the whole item
-// and the int32 C-in -(floor(S * v) - 2) is formed from it once per item — no per-class int32 table, no reload of C-in rows
-// in the middle of the N-tile loop when the size class changes.
+// window: one int16 threshold-plane value per size class and M-tile (mfma_common.h) is loaded once per item and becomes the
+// int32 C-in with one shift — no per-class int32 table, no reload of C-in rows in the middle of the N-tile loop when the size
+// class changes.
 // 16 waves per workgroup, one workgroup per CU, 128 VGPRs (4 waves per SIMD).  Measured and not adopted (dead ends): 12- and
 // 8-wave workgroups, 96 VGPRs (a fifth wave slot per SIMD left to other kernels).
 constexpr int V2S_NW = 16, V2S_OCC = 4;
@@ -216,13 +216,13 @@ __global__ __launch_bounds__(NW * 64, V2S_OCC) void scan_mfma2s_kernel(
 
     const uint32_t total_mt = *live_count;
     const uint32_t n_items = (total_mt + MT - 1) / MT;
-    float S_of_value[NV];  // unit of the threshold plane per value (= per size class of the super-class)
+    uint32_t shift_of_value[NV];  // log2 of the unit of the threshold plane per value (= per size class of the super-class)
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-        S_of_value[v] = 1.f;
+        shift_of_value[v] = 0;
 #pragma unroll
         for (int sg = 0; sg < MAX_PLANE_VALUES; sg++)
-            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) S_of_value[v] = P.S[sg];
+            if ((uint32_t)sg < segs.n && P.seg_value[sg] == (uint32_t)v) shift_of_value[v] = P.shift[sg];
     }
 
     // byte offsets of the lane's rows inside an M-tile's fragment, relative to the wave-uniform base (layouts: mfma_common.h)
@@ -262,13 +262,13 @@ __global__ __launch_bounds__(NW * 64, V2S_OCC) void scan_mfma2s_kernel(
             po[v] = plane_off[v];
             asm volatile("" : "+v"(po[v]));
         }
-        float nrm[MT][NV];  // threshold-plane values of the lane's own window px + r, one per size class
+        int16_t nrm[MT][NV];  // threshold-plane values of the lane's own window px + r, one per size class
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const uint8_t *np = reinterpret_cast<const uint8_t *>(P.planes + ((size_t)pp[mt] * Lrows + py[mt]) * Lpitch + px[mt]);  // wave-uniform
 #pragma unroll
-            for (int v = 0; v < NV; v++)  // (L - 2) / S rounded towards -inf; +inf = never
-                nrm[mt][v] = f16_bits_to_f32(*reinterpret_cast<const uint16_t *>(np + po[v]));
+            for (int v = 0; v < NV; v++)  // -floor((L - 2) / S) as int16 (a sign-extending load); -32768 = never
+                nrm[mt][v] = *reinterpret_cast<const int16_t *>(np + po[v]);
         }
         // K-step-major issue order: the N-tile loop's first MFMAs need K-step 0 of all M-tiles.  An address is a wave-uniform
         // 64-bit base (page, row, M-tile, K-step: scalar arithmetic) plus a 32-bit lane offset that never changes (lane_off[],
@@ -295,15 +295,15 @@ __global__ __launch_bounds__(NW * 64, V2S_OCC) void scan_mfma2s_kernel(
             }
         }
         take.request();  // the next item's ticket
-        // C-in of the lane's own window per size class (prefilter_cin, mfma_common.h; a window the class never emits at holds
-        // +inf, which comes out as an unreachable threshold).  M-tiles past the end of the enumeration repeat the last live one:
+        // C-in of the lane's own window per size class (prefilter_cin, mfma_common.h: one shift; a window the class never emits at
+        // holds -32768, an unreachable threshold).  M-tiles past the end of the enumeration repeat the last live one:
         // they are dropped where candidates are emitted (rare path), not here
         int cin[MT][NV];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                cin[mt][v] = prefilter_cin(S_of_value[v], nrm[mt][v]);
+                cin[mt][v] = prefilter_cin(shift_of_value[v], nrm[mt][v]);
             }
         v4i bf[KSTEPS];
 #pragma unroll

@@ -224,7 +224,7 @@ int focr_ctx_set_scan_cus(focr_ctx_t *ctx, unsigned max_cus);
 
 /* Which MFMA prefilter kernel FOCR_SCAN_MFMA uses.  Results are identical in every mode (conservative filters in front of
  * the same exact verify); only the speed differs.
- *   AUTO / ONE_STAGE  scan_mfma2s_kernel: A = templates, B = windows, C-in from the f16 threshold planes (scan_mfma2.hip)
+ *   AUTO / ONE_STAGE  scan_mfma2s_kernel: A = templates, B = windows, C-in from the int16 threshold planes (scan_mfma2.hip)
  *   LEGACY            round 1's kernel (A = windows) with per-class int32 threshold tables — what size classes with more
  *                     than 4 K-steps always use; selectable as a cross-check
  * (Value 2 was round 2's two-stage low-rank prefilter: exact, not faster, removed in round 3 — DESIGN.md, dead ends.) */
@@ -429,21 +429,19 @@ int focr_debug_set_tail_grid(focr_ctx_t *ctx, uint32_t num, uint32_t den);
  * box), per (window, template):
  *   sim[w * n_templates + t]   the exact similarity (double; NaN where the reference cannot emit: zero variance)
  *   d[w * n_templates + t]     G + C-in as the device forms them: the int8 MFMA sum over the kept columns plus
- *                              -(floor(S * plane) - 2) with the plane value of the window computed by the statistics
- *                              kernel's arithmetic (f32, f16 rounded towards -inf); the pair is a candidate iff d > 0
+ *                              the window's plane value (the statistics kernel's arithmetic: f32, then -floor((L - 2) / S)
+ *                              as int16) times S; the pair is a candidate iff d > 0
  * column_drop: as focr_ctx_set_column_drop.  info[4 * k ..] = {c_scale, e_max, rho_max, kept width} of size class k (in
  * order of first appearance), n_info = capacity of info in doubles. */
 int focr_debug_prefilter(const focr_template_t *templates, size_t n_templates, const uint8_t *needles, size_t needles_len,
                          int column_drop, const uint8_t *windows, size_t n_windows, uint32_t frame_w, uint32_t frame_h,
                          float threshold, double *sim, int64_t *d, double *info, size_t n_info);
 
-/* The threshold planes' directed rounding (f32 -> f16 bits towards -inf; above the f16 range: the largest finite f16 for
- * positive values, -inf for negative ones), host flavour, for the CPU tests. */
-void focr_debug_f16_down(const float *x, size_t n, uint16_t *out);
-/* The same rounding as the device performs it (the GPU tests compare them bit for bit): mode_form = 0 the generic device
- * form (convert towards zero + fix-up), 1 the statistics kernel's form (the waves' f16 rounding mode set to "towards -inf",
- * one conversion instruction). */
-int focr_debug_f16_down_device(focr_ctx_t *ctx, const float *x, size_t n, uint16_t *out, int mode_form);
+/* The threshold planes' values (mfma_common.h: -floor((L - 2) / 2^shift) as int16, clamped to +-32767), host flavour, for the
+ * CPU tests. */
+void focr_debug_plane_value(const float *L, size_t n, uint32_t shift, int16_t *out);
+/* The same as the device computes them (the GPU tests compare the two bit for bit). */
+int focr_debug_plane_value_device(focr_ctx_t *ctx, const float *L, size_t n, uint32_t shift, int16_t *out);
 
 #ifdef __cplusplus
 }

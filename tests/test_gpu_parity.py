@@ -81,29 +81,31 @@ def test_device_f64_divide_sqrt_are_correctly_rounded(scanner):
     assert same.all(), f"{(~same).sum()} of {cnt} differ"
 
 
-def test_threshold_plane_rounding_device_equals_host(scanner):
-    """f32 -> f16 towards -inf: the host flavour the CPU tests model the prefilter with (mfma_common.h, f16_down), the generic device
-    flavour (v_cvt_pkrtz + fix-up) and the statistics kernel's (round 4: the waves' f16 rounding mode set to "towards -inf", one
-    v_cvt_f16_f32) agree bit for bit — subnormals, signed zeros and the values beyond the f16 range a +-1e30 threshold produces
-    included — and never round up."""
+def test_threshold_plane_values_device_equals_host(scanner):
+    """The threshold planes' values, -floor((L - 2) / S) as int16 (mfma_common.h: plane_value): the host flavour the CPU tests model the
+    prefilter with and the device's agree bit for bit — huge thresholds of either sign (a +-1e30 --threshold), infinities and values
+    at the clamp included — and the threshold they stand for never lies above L - 2."""
     import ctypes as C
 
     rng = np.random.default_rng(9)
-    x = np.concatenate([rng.normal(0, 1, 400000) * 10.0 ** rng.integers(-9, 5, 400000),
-                        rng.normal(0, 1, 20000) * 10.0 ** rng.integers(4, 30, 20000),  # beyond 65504: largest finite f16 / -inf
-                        [0.0, -0.0, 1.0, -1.0, 65000.0, -65000.0, 65504.0, -65504.0, 65519.9, -65519.9, 65520.0, -65520.0, 65536.0, -65536.0, 1e9, -1e9,
-                         np.inf, -np.inf, 6e-8, -6e-8, 1e-9, -1e-9, 2.0 ** -14, -(2.0 ** -14), 2.0 ** -24, -(2.0 ** -25)]]).astype(np.float32)
+    x = np.concatenate([rng.normal(0, 1, 400000) * 10.0 ** rng.integers(0, 7, 400000),
+                        rng.normal(0, 1, 20000) * 10.0 ** rng.integers(6, 30, 20000),
+                        [0.0, -0.0, 1.0, 2.0, 3.0, -1.0, 65.9, 66.0, 66.1, -61.9, -62.0, -62.1, 2097150.0, 2097152.0, 2097217.9, 2097218.0, -2097150.0, 1e9, -1e9,
+                         np.inf, -np.inf, 3.0e38, -3.0e38]]).astype(np.float32)
     x = np.ascontiguousarray(x)
-    host = np.zeros(len(x), np.uint16)
-    scanner._lib.focr_debug_f16_down(x.ctypes.data_as(C.c_void_p), len(x), host.ctypes.data_as(C.c_void_p))
-    with np.errstate(over="ignore"):
-        assert (host.view(np.float16).astype(np.float64) <= x.astype(np.float64)).all()
-    in_range = np.abs(x) < 65000
-    for form in (0, 1):
-        dev = np.zeros(len(x), np.uint16)
-        scanner._ck(scanner._lib.focr_debug_f16_down_device(scanner._h, x.ctypes.data_as(C.c_void_p), len(x), dev.ctypes.data_as(C.c_void_p), form))
-        sel = in_range if form == 0 else np.ones(len(x), bool)  # the generic form is specified inside the f16 range only
-        assert np.array_equal(host[sel], dev[sel]), (form, x[sel][host[sel] != dev[sel]][:8], host[sel][host[sel] != dev[sel]][:8], dev[sel][host[sel] != dev[sel]][:8])
+    for shift in (5, 6, 9, 14):
+        host = np.zeros(len(x), np.int16)
+        dev = np.zeros(len(x), np.int16)
+        scanner._lib.focr_debug_plane_value(x.ctypes.data_as(C.c_void_p), len(x), shift, host.ctypes.data_as(C.c_void_p))
+        scanner._ck(scanner._lib.focr_debug_plane_value_device(scanner._h, x.ctypes.data_as(C.c_void_p), len(x), shift, dev.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(host, dev), (shift, x[host != dev][:8], host[host != dev][:8], dev[host != dev][:8])
+        S = float(1 << shift)
+        thr = -host.astype(np.float64) * S  # the threshold the plane value stands for
+        inside = np.abs(x.astype(np.float64) - 2.0) < 32767.0 * S
+        assert (thr[inside] <= x[inside].astype(np.float64) - 2.0 + 1e-3 * np.abs(x[inside])).all()  # (f32 rounding of L - 2)
+        assert (thr[inside] > x[inside].astype(np.float64) - 2.0 - S - 1e-3 * np.abs(x[inside])).all()
+        assert (host[~inside & (x > 0)] == -32767).all() and (host[~inside & (x < 0)] == 32767).all()
+        assert host.min() >= -32767  # -32768 is the "never" value: a threshold never maps to it
 
 
 def test_compat_symbols_on_golden_vectors(kernel_cases):

@@ -194,16 +194,15 @@ def test_dropped_column_adversarial():
         assert not missed.any(), (thr, int(missed.sum()), sim[missed][:5], d[missed][:5])
 
 
-def test_f16_round_down_helper_matches_numpy():
-    """The plane's directed rounding (f32 -> f16 towards -inf) against numpy on a sweep of values incl. subnormals."""
+def test_plane_value_helper_matches_numpy():
+    """The plane's value, -floor((L - 2) / S) as int16 clamped to +-32767, against numpy on a sweep of thresholds."""
     lib = N.hip()
     rng = np.random.default_rng(1)
-    x = np.concatenate([rng.normal(0, 1, 20000) * 10.0 ** rng.integers(-9, 5, 20000), [0.0, -0.0, 1.0, -1.0, 65503.9, -65503.9, 6e-8, -6e-8, 1e-9, -1e-9]]).astype(np.float32)
-    x = x[np.abs(x) < 65000]
-    out = np.zeros(len(x), np.uint16)
-    lib.focr_debug_f16_down(x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p))
-    got = out.view(np.float16).astype(np.float64)
-    h = x.astype(np.float16)  # nearest
-    down = np.where(h.astype(np.float64) > x.astype(np.float64), np.nextafter(h, np.float16(-np.inf)), h).astype(np.float64)
-    assert np.array_equal(got, down), (x[got != down][:5], got[got != down][:5], down[got != down][:5])
-    assert (got <= x.astype(np.float64)).all()
+    x = np.concatenate([rng.normal(0, 1, 20000) * 10.0 ** rng.integers(0, 8, 20000), [0.0, 2.0, 65.9, 66.0, -61.9, -62.0, 1e9, -1e9, np.inf, -np.inf]]).astype(np.float32)
+    for shift in (5, 6, 10):
+        out = np.zeros(len(x), np.int16)
+        lib.focr_debug_plane_value(x.ctypes.data_as(C.c_void_p), len(x), shift, out.ctypes.data_as(C.c_void_p))
+        with np.errstate(invalid="ignore", over="ignore"):
+            t = np.floor((x - np.float32(2.0)).astype(np.float32) * np.float32(2.0 ** -shift))
+        want = (-np.clip(t, -32767.0, 32767.0)).astype(np.int16)
+        assert np.array_equal(out, want), (shift, x[out != want][:5], out[out != want][:5], want[out != want][:5])
