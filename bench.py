@@ -849,6 +849,9 @@ def main():
         dev_iv = [t_["device_gap_ms"] for t_ in ticket_log[1:] if t_["device_gap_ms"] >= 0]
         sub_iv = [(b_ - a_) / 1e3 for a_, b_ in zip(sub, sub[1:])]
         lead = [(t_["done_us"] - t_["enqueue_end_us"]) / 1e3 for t_ in ticket_log]  # how long a batch sat fully queued before its results were seen
+        if os.environ.get("FOCR_BENCH_DUMP_TICKETS"):  # every retired batch's stamps, for a look at one run's rhythm
+            with open(os.environ["FOCR_BENCH_DUMP_TICKETS"], "w") as f_:
+                json.dump(ticket_log, f_)
         out["step_stats"] = {
             "batches": len(ticket_log),
             "first_completion_ms": round((done[0] - sub[0]) / 1e3, 3),

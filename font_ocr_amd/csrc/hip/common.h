@@ -211,6 +211,7 @@ struct focr_ctx {
     uint64_t *d_hit_keys = nullptr, *d_hit_keys_alt = nullptr;
     float *d_hit_sims = nullptr, *d_hit_sims_alt = nullptr;
     uint32_t *d_counter = nullptr;  // u64 [0] hits, u64 [1] candidates, u32 [8..47] live M-tile counts, then the scan kernels' item queues
+    unsigned stats_turn = 0;        // this batch's place in the device's chain of statistics launches (launch_scan_mfma)
     uint32_t scan_queues_used = 0;  // item queues handed out since the last reset (launch_scan_mfma)
     size_t cand_capacity = 0, cand_alt_capacity = 0;
     uint64_t *d_cand = nullptr, *d_cand_alt = nullptr;

@@ -640,6 +640,7 @@ struct ScanTurns {
     bool init = false;
 };
 static ScanTurns scan_turns[64];
+static ScanTurns stats_turns[64];  // the same for the statistics in front of the scans
 
 int launch_scan_mfma(focr_ctx *c, float threshold) {
     const double thr_d = (double)threshold;  // src/ncc.cpp:83, 288
@@ -726,6 +727,23 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         uint64_t *live_list = (uint64_t *)c->scan_live_list.ensure(c, (tiles_total + 16) * 8);
         if (!live || !live_list) return fail(c, FOCR_ERR_NOMEM, "scan_mfma: hipMalloc failed");
         if (!clear.add(live, tiles_total + 16)) return fail(c, FOCR_ERR_INVALID, "scan_mfma: clear list full or region too large");
+        // The statistics of the batches of one device take turns too (an event chain like the scan kernels' below): two lanes that
+        // start their statistics at the same moment — a pipeline filling up from a drained state does that — share the free CUs,
+        // finish together, then wait for their scan turns one behind the other, and their tails overlap again: a second steady state
+        // with the same work and 7 % less throughput (two batches completing together, then 2.5 and 3.0 ms: DESIGN.md section 5,
+        // "two rhythms").  In the staggered state a batch's statistics never meet another's, and the chain costs nothing.
+        static const bool stats_chain = getenv("FOCR_NO_STATS_CHAIN") == nullptr;
+        ScanTurns &st = stats_turns[(unsigned)c->device % 64];
+        if (stats_chain) {
+            std::lock_guard<std::mutex> turn(st.mu);
+            if (!st.init) {
+                for (hipEvent_t &e : st.ev) FOCR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                st.init = true;
+            }
+            if (st.n) FOCR_HIP(c, hipStreamWaitEvent(c->stream, st.ev[(st.n - 1) % 8], 0));
+            // (the event of THIS batch's statistics is recorded below, under the same lock order: reserve its place now)
+            c->stats_turn = st.n++;
+        }
         if ((rc = launch_clear(c, clear))) return rc;
         // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
         const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // int16 values per plane
@@ -791,6 +809,10 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             FOCR_HIP(c, hipGetLastError());
         }
         FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
+        if (stats_chain) {
+            std::lock_guard<std::mutex> turn(st.mu);
+            FOCR_HIP(c, hipEventRecord(st.ev[c->stats_turn % 8], c->stream));
+        }
         // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget).
         // With several contexts in flight on one GPU the persistent scan kernels take turns: each context's launches
         // wait (on the device, hipStreamWaitEvent) for the previous context's to finish.  Two of them sharing the

@@ -1,10 +1,10 @@
 # A/B on one box: tools/bin/libfocr_hip_base.so (tools/build_base_lib.sh <commit>) against this tree's library, alternating; extra bench.py arguments pass through
 set -o pipefail
 mkdir -p gpurun_out
-for rep in 1 2 3 4; do
+for rep in 1 2 3 4 5 6; do
   for which in base new; do
     if [ $which = base ]; then export FOCR_HIP_LIB=$PWD/tools/bin/libfocr_hip_base.so; else unset FOCR_HIP_LIB; fi
-    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-e2e --steps 300 "$@" > gpurun_out/ab.json 2>/dev/null
+    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-e2e --no-extra-legs --steps 300 "$@" > gpurun_out/ab.json 2>/dev/null
     python3 -c "import json;d=json.load(open('gpurun_out/ab.json'));print('$which:', d['value'], d['ms_per_step'], d['roofline']['avg_kernel_ms'])"
   done
 done
