@@ -8,9 +8,12 @@
 // reference's own call pattern — hundreds of templates over one page — pays the
 // 13 B/px of PCIe traffic once per page and size class, not once per call.
 // Throughput proper goes through the batched API.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -76,22 +79,27 @@ __global__ void compat_pack(const uint64_t *__restrict__ keys, const float *__re
     out[i] = m;
 }
 
-// 64-bit content hash (4 interleaved multiply-rotate lanes over 8-byte words): ~10 GB/s on one core, i.e. 0.5 ms for the
-// 5.7 MB a 608x720 page's inputs have — against ~2 ms to push them over PCIe from pageable memory
+// 64-bit content hash: 8 independent multiply-xorshift lanes over 8-byte words (the multiplies of eight lanes overlap: 14-25 GB/s
+// on one core, twice the four-lane form of rounds 1-4) — ~0.25 ms for the 5.7 MB a 608x720 page's inputs have, against ~2 ms to
+// push them over PCIe from pageable memory.  Still the largest item of a call (the kernel itself takes a few microseconds).
 static uint64_t content_hash(const void *p, size_t n) {
     const uint8_t *b = (const uint8_t *)p;
-    uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0x2545f4914f6cdd1dull};
+    uint64_t h[8] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0x2545f4914f6cdd1dull,
+                     0xd6e8feb86659fd93ull, 0xa0761d6478bd642full, 0xe7037ed1a0b428dbull, 0x8ebc6af09c88c6e3ull};
     size_t i = 0;
-    for (; i + 32 <= n; i += 32)
-        for (int k = 0; k < 4; k++) {
-            uint64_t v;
-            memcpy(&v, b + i + 8 * k, 8);
-            h[k] = (h[k] ^ v) * 0x9fb21c651e98df25ull;
-            h[k] = (h[k] << 29) | (h[k] >> 35);
+    for (; i + 64 <= n; i += 64) {
+        uint64_t v[8];
+        memcpy(v, b + i, 64);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            h[k] = (h[k] ^ v[k]) * 0x9fb21c651e98df25ull;
+            h[k] ^= h[k] >> 29;
         }
+    }
     uint64_t tail = 0;
     for (int sh = 0; i < n; i++, sh = (sh + 8) & 63) tail ^= (uint64_t)b[i] << sh;
-    uint64_t r = h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ tail ^ (uint64_t)n * 0xd6e8feb86659fd93ull;
+    uint64_t r = tail ^ (uint64_t)n * 0xd6e8feb86659fd93ull;
+    for (int k = 0; k < 8; k++) r = (r ^ h[k]) * 0x9fb21c651e98df25ull + (uint64_t)k;
     r ^= r >> 32;
     r *= 0xd6e8feb86659fd93ull;
     return r ^ (r >> 29);
@@ -110,6 +118,13 @@ struct CompatState {
     uint16_t *d_se = nullptr;
     focr_match_t *d_out = nullptr;
     size_t px_alloc = 0, rows_alloc = 0, out_alloc = 0;
+    // the call's hits land in page-locked host memory as the kernel finds them (a call emits tens to a few thousand): ONE wait per
+    // call, then a host sort of those few — instead of a count read-back, a device radix sort (a dozen launches), a pack kernel and
+    // a second read-back.  A call with more hits than the block holds takes the device path.
+    unsigned long long *h_count = nullptr;  // [0]: hits found (copied out of device memory behind the kernel)
+    uint64_t *h_keys = nullptr;
+    float *h_sims = nullptr;
+    static constexpr size_t PIN_HITS = 1u << 16;
     // deliberately no destructor: thread-exit / process-exit order against the HIP runtime's own
     // teardown is unspecified, and the driver reclaims everything anyway.
 };
@@ -210,6 +225,42 @@ static size_t compat_call(uint8_t *reference, size_t r_w, size_t r_h, uint8_t *n
     }
     CK(hipMemcpyAsync(tl.d_needle, needle_u8, n_h * N, hipMemcpyHostToDevice, c->stream));
 
+    if (!tl.h_count) {
+        void *blk = nullptr;
+        if (hipHostMalloc(&blk, 64 + CompatState::PIN_HITS * 12, hipHostMallocDefault) == hipSuccess) {
+            tl.h_count = (unsigned long long *)blk;
+            tl.h_keys = (uint64_t *)((char *)blk + 64);
+            tl.h_sims = (float *)((char *)blk + 64 + CompatState::PIN_HITS * 8);
+        }
+    }
+    if (tl.h_count) {  // the fast form: hits straight into page-locked host memory
+        // (the counter stays in device memory — an atomic per hit across PCIe is neither fast nor everywhere supported — and is copied
+        // out behind the kernel; the hits themselves are plain stores into the page-locked block)
+        CK(hipMemsetAsync(c->d_counter, 0, 64 * sizeof(uint32_t), c->stream));
+        dim3 grid((unsigned)((r_w + 255) / 256), (unsigned)(y_searches - 1));
+        hipLaunchKernelGGL((compat_kernel<N>), grid, dim3(256), 0, c->stream, tl.d_ref, (uint32_t)r_w, (uint32_t)r_h,
+                           reinterpret_cast<const uint32_t *>(tl.d_needle), (uint32_t)n_w, (uint32_t)n_h, tl.d_ps, tl.d_pr, tl.d_se, (double)s_n, n_recip,
+                           rnorm_n, (double)threshold, tl.h_keys, tl.h_sims, (unsigned long long *)c->d_counter, (unsigned long long)CompatState::PIN_HITS);
+        CK(hipGetLastError());
+        CK(hipMemcpyAsync(tl.h_count, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        CK(hipStreamSynchronize(c->stream));
+        const unsigned long long cnt = *tl.h_count;
+        if (cnt <= CompatState::PIN_HITS) {
+            if (cnt == 0) return 0;
+            // (y, x) order, src/ncc.cpp:302-375: the key is y << 16 | x
+            std::vector<std::pair<uint64_t, float>> hits((size_t)cnt);
+            for (size_t i = 0; i < (size_t)cnt; i++) hits[i] = {tl.h_keys[i], tl.h_sims[i]};
+            std::sort(hits.begin(), hits.end(), [](const std::pair<uint64_t, float> &a, const std::pair<uint64_t, float> &b) { return a.first < b.first; });
+            const size_t keep = std::min<size_t>((size_t)cnt, n_out);  // src/ncc.cpp:225-227, 371-373
+            for (size_t i = 0; i < keep; i++) {
+                out[i].x = (uint16_t)(hits[i].first & 0xffff);
+                out[i].y = (uint16_t)((hits[i].first >> 16) & 0xffff);
+                out[i].similarity = hits[i].second;
+            }
+            return keep;
+        }
+        // more hits than the block holds (very low thresholds): the device path below counts and sorts them all
+    }
     size_t want = std::max<size_t>(c->hit_capacity, std::max<size_t>(1u << 16, n_out * 4));
     for (int attempt = 0; attempt < 3; attempt++) {
         if (ensure_hit_capacity(c, want) != FOCR_OK) return 0;

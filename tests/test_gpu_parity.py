@@ -1185,12 +1185,36 @@ def test_compat_symbols_in_the_reference_call_pattern(bank_x2):
     if O.have_ref():
         assert t_gpu < t_ref, (t_gpu, t_ref)
     print(f"380 drop-in calls: {t_gpu * 1e3:.0f} ms on the device path, {t_ref * 1e3:.0f} ms with the reference kernel on one core")
+    # ... and as the reference's host calls them: from a pool of threads, one page each (rayon par_iter, src/ncc.rs:839-847); every
+    # calling thread has its own stream and resident inputs
+    import threading
+
+    n_thr = 8
+    searchers = [Searcher(inv) for _ in range(n_thr)]
+    outs = [None] * n_thr
+
+    def work(j):
+        outs[j] = [searchers[j].search_c_u8(bank_x2.needle(t), stats[bank_x2.needle(t).shape], 0.8) for t in range(len(bank_x2))]
+
+    for rep_ in range(2):  # the first round creates the threads' contexts
+        ths = [threading.Thread(target=work, args=(j,)) for j in range(n_thr)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        t_pool = time.perf_counter() - t0
+    for j in range(n_thr):
+        for t, (g, w) in enumerate(zip(outs[j], want)):
+            assert g.tobytes() == w.tobytes(), (j, t)
+    print(f"{n_thr} calling threads, one page each: {t_pool * 1e3:.0f} ms = {n_thr * 608 * 720 / t_pool / 1e6:.1f} Mpx/s through the drop-in symbols "
+          f"(one thread: {608 * 720 / t_gpu / 1e6:.1f} Mpx/s)")
 
 
 def test_pipeline_ticket_gate_never_blocks_on_failed_or_direct_batches():
-    """tools/gate_check.py: the lanes queue their scans in ticket order (TurnGate); a batch that fails before its scan and a
-    direct-mode batch (no scan turn) between MFMA batches must not hold the later tickets up.  Child process with a time limit:
-    a deadlock must fail, not hang."""
+    """tools/gate_check.py: the executor queues its batches in ticket order; a batch that fails before its scan and a
+    direct-mode batch (no turn in the scan chain) between MFMA batches must not hold the later tickets up.  Child process with a
+    time limit: a deadlock must fail, not hang."""
     import os
     import subprocess
     import sys

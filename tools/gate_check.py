@@ -1,6 +1,7 @@
-"""The executor's ticket-order gate (TurnGate, common.h) must never hold the lanes up: a batch that fails before its scan, a batch in
-direct mode (no MFMA scan turn), and MFMA batches around them all complete, in order, with the right lists.  Run as a child
-process with a time limit by tests/test_gpu_parity.py (a deadlock would otherwise hang the suite)."""
+"""The executor queues its batches in ticket order (pipe.hip; rounds 3-4: a host-side gate in front of every scan launch).  Nothing
+may hold the later tickets up: a batch that fails before its scan, a batch in direct mode (no turn in the scan kernels' chain), and
+MFMA batches around them all complete, in order, with the right lists.  Run as a child process with a time limit by
+tests/test_gpu_parity.py (a deadlock would otherwise hang the suite)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +14,11 @@ pages = synth_pages(bank, 4, 320, 120)
 pipe = Pipeline(0, 3)
 pipe.set_bank(bank)
 t1 = pipe.submit(pages[:2], 0.8, mode=SCAN_MFMA)
-t2 = pipe.submit(None, 0.8, mode=SCAN_MFMA)      # lane 2 holds no pages yet: fails before any kernel
+t2 = pipe.submit(None, 0.8, mode=SCAN_MFMA)      # context 2 holds no pages yet: fails before any kernel
 t3 = pipe.submit(pages[2:], 0.8, mode=SCAN_DIRECT)  # no MFMA scan, so no turn to take
 ref = {}
 sc = pipe.wait(t1); ref[1] = sc.matches()[1].copy(); pipe.release(t1)
-t4 = pipe.submit(pages[2:], 0.8, mode=SCAN_MFMA)    # lane 1 again (a submit blocks until its lane's previous ticket is released)
+t4 = pipe.submit(pages[2:], 0.8, mode=SCAN_MFMA)    # (a submit blocks only while its own context's previous ticket is unreleased)
 failed = False
 try:
     pipe.wait(t2)
