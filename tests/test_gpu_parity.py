@@ -862,6 +862,59 @@ def test_pipeline_executor_orders_and_matches_oracle(bank_x2):
         pipe.close()
 
 
+def test_pipeline_two_threads_and_close_with_batches_outstanding(bank_x2):
+    """The executor's API allows one thread to submit and another to retire (wait / read / release); and destroying an executor with
+    batches still queued or running must finish them and return (no hang, no crash).  Child-free: a deadlock here would hang the
+    suite, so the retiring thread is joined with a time limit."""
+    import threading
+
+    from font_ocr_amd.searcher import Pipeline
+
+    n_batches = 40
+    pages = [np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 3000 + 2 * (b % 5) + p, 300, 110) for p in range(2)]) for b in range(5)]
+    want = []
+    with Scanner(0) as sc:
+        sc.set_bank(bank_x2)
+        for pg in pages:
+            sc.set_pages(pg)
+            sc.scan(0.8, 1024, SCAN_MFMA)
+            sc.process_hits(0.95, 5)
+            want.append((sc.matches()[1].tobytes(), sc.lines_flat().tobytes()))
+    pipe = Pipeline(0, 3)
+    errs, tickets, cv = [], [], threading.Condition()
+
+    def retire():
+        try:
+            for b in range(n_batches):
+                with cv:
+                    cv.wait_for(lambda: len(tickets) > b, timeout=60)
+                    t = tickets[b]
+                s2 = pipe.wait(t)
+                got = (s2.matches()[1].tobytes(), s2.lines_flat().tobytes())
+                if got != want[b % 5]:
+                    errs.append(f"batch {b} differs")
+                pipe.release(t)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    try:
+        pipe.set_bank(bank_x2)
+        th = threading.Thread(target=retire)
+        th.start()
+        for b in range(n_batches):  # submit blocks while the batch's context is unreleased: the other thread releases
+            t = pipe.submit(pages[b % 5], 0.8)
+            with cv:
+                tickets.append(t)
+                cv.notify_all()
+        th.join(timeout=120)
+        assert not th.is_alive(), "the retiring thread is stuck"
+        assert not errs, errs
+        for b in range(len(pipe.scanners)):  # six batches queued / running, nobody waits for them
+            pipe.submit(pages[b % 5], 0.8)
+    finally:
+        pipe.close()  # finishes them first
+
+
 def test_pipeline_chars_out_with_estimated_and_redone_batches(bank_x2):
     """chars_out of focr_pipe_submit: the characters' copy into the caller's device buffer is queued behind process_hits on the lane's
     stream (a kernel that reads their number on the device) — also when the batch runs on size estimates, and a batch whose estimates
