@@ -82,6 +82,8 @@ __host__ __device__ inline float sqrt_fast(float x) {
 __host__ __device__ inline float threshold_f32(const PlaneParams &p, float Vf, float Wf) {
     return __builtin_fmaf(-p.crk, sqrt_fast(Wf), p.kq * sqrt_fast(Vf));
 }
+// the same for a class without a dropped column (crk = 0, W = 0): fma(-0, 0, x) = x, bit for bit — two instructions less
+__host__ __device__ inline float threshold_f32_nodrop(const PlaneParams &p, float Vf) { return p.kq * sqrt_fast(Vf); }
 // An UPPER bound of W = n_k^2 * dnorm^2 = n_k^2 q2 + D s_k^2 - 2 n_k s_k q1 in f32 (the exact value needs 64-bit integer
 // multiplies, quarter-rate instructions on the vector unit; this is five full-rate ones).  Every factor is an integer below
 // 2^24, so each of the three products carries at most two roundings and the sum three more: |error| < 7 * 2^-24 * (t1 + t2 + t3)
@@ -104,7 +106,9 @@ __host__ __device__ inline int32_t threshold_negL(float Lf) {
 // (the model) and on the device (exact scaling by a power of two, floor, an exact conversion): bit-identical by construction,
 // checked by tests/test_gpu_parity.py::test_threshold_plane_values_device_equals_host.
 __host__ __device__ inline int16_t plane_value(const PlaneParams &p, float Lf) {
-    float t = __builtin_floorf((Lf - 2.0f) * p.inv_S);
+    // (L - 2) / S in one fused step: S is a power of two, so the product and the constant are exact and the single rounding is that
+    // of L - 2 scaled — bit-identical to (Lf - 2.0f) * inv_S, one instruction less
+    float t = __builtin_floorf(__builtin_fmaf(Lf, p.inv_S, -2.0f * p.inv_S));
     t = __builtin_fminf(__builtin_fmaxf(t, -32767.0f), 32767.0f);
     return (int16_t)(-(int)t);
 }

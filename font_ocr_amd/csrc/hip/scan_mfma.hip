@@ -86,8 +86,9 @@ int launch_clear(focr_ctx *c, const ClearList &l) {
 // mfma_common.h, "threshold planes"); window is live  <=>  V > 0, which is exactly the reference's "norm > 0"
 // (src/ncc.rs:309: (f64)s2 - (f64)(s*s)/(f64)n is > 0 iff V > 0, = 0 iff V = 0, because V/n >= 1/n is far above the
 // rounding error of the division).
-//   DROP: the class's last column is bounded, not multiplied: the thread also slides the sums of that one column (bytes of
-//         the tile) down, which gives the kept box's sums and W.
+//   DROP: the class's last column is bounded, not multiplied: the horizontal sums run over the KEPT width (round 5: two dwords
+//         instead of three for BASELINE configs[1]'s 9-wide class) and the thread also slides the sums of the dropped column (bytes
+//         of the tile) down; the full box's sums are the two added, W comes from both.
 //   PAIR: the kept box is itself a size class of the pass (BASELINE configs[1]: 8x15 beside 9x15): its plane comes out of
 //         the same launch (its statistics are the kept box's), one launch instead of two.
 constexpr int STX = 64, STY = 32, SLDW = 21;  // 32 window rows per block (64 = less halo, fewer blocks per CU: measured, no gain)
@@ -111,7 +112,7 @@ __device__ __forceinline__ void stats_store(const StatsOut &o, IDX idx, bool emi
     }
 }
 
-template <int NDW, bool SMALLN, int OUT, bool DROP, bool PAIR>
+template <int NDW, bool SMALLN, int OUT, bool DROP, bool PAIR>  // NDW: dwords of the KEPT width (n_w, or n_w - 1 with DROP)
 __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc,
                                                     uint32_t r_w, uint32_t r_h, uint32_t n_w, uint32_t n_h, const StatsOut A,
                                                     const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             }
         return;
     }
+    const uint32_t kw = DROP ? n_w - 1 : n_w;  // the kept width: what the horizontal sums cover
     {  // horizontal sums
         const uint32_t lane = threadIdx.x & 63, cb = lane >> 2, sh = lane & 3;
         for (uint32_t r = threadIdx.x >> 6; r < rows; r += 4) {
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
             for (int k = 0; k < NDW; k++) {
                 uint32_t lo = tile[r][cb + k], hi = tile[r][cb + k + 1];
                 uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                uint32_t keep = n_w >= (uint32_t)(4 * k + 4) ? 0xffffffffu
-                                : (n_w <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (n_w - 4 * k))) - 1u));
+                uint32_t keep = kw >= (uint32_t)(4 * k + 4) ? 0xffffffffu
+                                : (kw <= (uint32_t)(4 * k) ? 0u : ((1u << (8 * (kw - 4 * k))) - 1u));
                 w &= keep;
                 h = __builtin_amdgcn_udot4(w, 0x01010101u, h, false);
                 h2 = __builtin_amdgcn_udot4(w, w, h2, false);
@@ -176,10 +178,10 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     const uint32_t r0 = strip * PER;
     // the class's last column as bytes of the tile (DROP): column x + n_w - 1 of the page = byte col + n_w - 1 of a tile row
     const uint8_t *lastc = reinterpret_cast<const uint8_t *>(&tile[0][0]) + col + n_w - 1;
-    uint32_t s = 0, s2 = 0, q1 = 0, q2 = 0;
+    uint32_t s_k = 0, s2_k = 0, q1 = 0, q2 = 0;  // sums of the kept box and of the dropped column
     for (uint32_t j = 0; j < n_h; j++) {
-        s += H[r0 + j][col];
-        s2 += H2[r0 + j][col];
+        s_k += H[r0 + j][col];
+        s2_k += H2[r0 + j][col];
         if (DROP) {
             const uint32_t b = lastc[(size_t)(r0 + j) * (SLDW * 4)];
             q1 += b;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
         if (y < Lrows) {
             // V = n*s2 - s*s, exact; V > 0 <=> the reference's rnorm is finite.  SMALLN (n <= 256): both products
             // fit 32 bits (n*s2 <= n^2 * 255^2 < 2^32, s <= 255 n < 2^16).
+            const uint32_t s = DROP ? s_k + q1 : s_k, s2 = DROP ? s2_k + q2 : s2_k;  // the full box
             bool nz;
             float Vf;
             if (SMALLN) {  // n <= 256: n, s, s2 < 2^24 -> full-rate 24-bit multiplies (a 32-bit v_mul_lo is a quarter-rate instruction)
@@ -214,11 +217,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 Vf = (float)V;
             }
             const bool y_ok = y >= 1 && y + n_h <= r_h;
-            const uint32_t s_k = s - q1, s2_k = s2 - q2;  // the kept box (DROP)
-            const float Wf = DROP ? dropped_column_W_upper(n_k, n_h, s_k, q1, q2) : 0.f;
             const bool emit = x_ok && y_ok && nz;
             bool any = emit;
-            stats_store<OUT, idx_t>(A, idx, emit, threshold_f32(A.p, Vf, Wf));
+            stats_store<OUT, idx_t>(A, idx, emit, DROP ? threshold_f32(A.p, Vf, dropped_column_W_upper(n_k, n_h, s_k, q1, q2)) : threshold_f32_nodrop(A.p, Vf));
             if (PAIR) {  // the kept box as a size class of its own: (n_w - 1) x n_h, nothing dropped
                 bool nzk;
                 float Vkf;
@@ -233,14 +234,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
                 }
                 const bool emit_k = xk_ok && y_ok && nzk;
                 any |= emit_k;
-                stats_store<OUT, idx_t>(B, idx, emit_k, threshold_f32(B.p, Vkf, 0.f));
+                stats_store<OUT, idx_t>(B, idx, emit_k, threshold_f32_nodrop(B.p, Vkf));
             }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(any);
             if (mark_lane && ((lm >> col) & 0xffffu) && y >= 1 && y <= n_rows) live[live_i + k * mtx - mtx] = 1;
         }
         if (k + 1 < PER) {  // slide down one row
-            s += H[r0 + k + n_h][col] - H[r0 + k][col];
-            s2 += H2[r0 + k + n_h][col] - H2[r0 + k][col];
+            s_k += H[r0 + k + n_h][col] - H[r0 + k][col];
+            s2_k += H2[r0 + k + n_h][col] - H2[r0 + k][col];
             if (DROP) {
                 const uint32_t bi = lastc[(size_t)(r0 + k + n_h) * (SLDW * 4)], bo = lastc[(size_t)(r0 + k) * (SLDW * 4)];
                 q1 += bi - bo;
@@ -616,7 +617,7 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
         else if (drop) small ? launch(stats_kernel<NDW, true, OUT, true, false>) : launch(stats_kernel<NDW, false, OUT, true, false>);     \
         else small ? launch(stats_kernel<NDW, true, OUT, false, false>) : launch(stats_kernel<NDW, false, OUT, false, false>);             \
         break;
-    switch ((sc.n_w + 3) / 4) {
+    switch ((sc.keep_w + 3) / 4) {  // dwords of the kept width (keep_w = n_w unless the class's last column is dropped)
         STATS_CASE(1) STATS_CASE(2) STATS_CASE(3) STATS_CASE(4)
         default: return fail(c, FOCR_ERR_INVALID, "scan_mfma: unsupported box width");
     }

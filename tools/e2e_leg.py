@@ -29,8 +29,9 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 bank = Bank.load(os.path.join(root, "tests", "golden", "bank_dejavu13_ascii95_x2.bin"))
 pipe = Pipeline(0, a.in_flight)
 pipe.set_bank(bank)
+N_OUT = len(pipe.scanners)  # batches outstanding at the host: lanes x contexts per lane
 pages = synth_pages(bank, P, R_W, R_H)
-n_pins = a.pins or a.in_flight
+n_pins = a.pins or N_OUT
 pins = []
 for j in range(n_pins):
     pin = PinnedPages(P, R_H, R_W)
@@ -40,26 +41,27 @@ for j in range(n_pins):
 
 def run(n, resident):
     tickets = deque()
-    ahead = 0 if (resident or a.no_prefetch) else min(a.in_flight, n)  # batches announced ahead of their submit (focr_pipe_prefetch)
+    ahead = 0 if (resident or a.no_prefetch) else min(N_OUT, n)  # batches announced ahead of their submit (focr_pipe_prefetch)
     for k in range(ahead):
         pipe.prefetch(pins[k % n_pins].array)
     for k in range(n):
-        if len(tickets) == a.in_flight:
+        if len(tickets) == N_OUT:
             t = tickets.popleft()
             pipe.wait(t)
             pipe.release(t)
+        if k + 1 == n:
+            pipe.announce_last()
         tickets.append(pipe.submit(None if resident else pins[k % n_pins].array, 0.8, 1024, SCAN_MFMA, True, 0.95, 5))
         if ahead and k + ahead < n:
             pipe.prefetch(pins[(k + ahead) % n_pins].array)
-    pipe.end_of_stream()
     while tickets:
         t = tickets.popleft()
         pipe.wait(t)
         pipe.release(t)
 
 
-run(2 * a.in_flight, False)  # every lane holds pages, sizes are known
-run(4 * a.in_flight, a.resident)
+run(2 * N_OUT, False)  # every context holds pages, sizes are known
+run(4 * N_OUT, a.resident)
 t0 = time.perf_counter()
 run(a.steps, a.resident)
 dt = time.perf_counter() - t0
