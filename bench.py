@@ -545,6 +545,9 @@ def main():
         kern_, phase_ = (kern, phase) if timed else ({}, {})
         tt = pipe.ticket_times(t)
         if timed:
+            if os.environ.get("FOCR_BENCH_DUMP_TICKETS"):  # + where the batch's phases lie on the device's clock
+                tt.update(c_.phase_stamps())
+                tt["ticket"] = t
             ticket_log.append(tt)
         for li in c_.launches():  # launches of one kernel over different bank chunks are different launches: key by their work too
             k = kern_.setdefault((li["name"], li["alg_macs"]), dict(ms=0.0, n=0, alg=li["alg_macs"], issued=li["issued_macs"]))

@@ -20,6 +20,7 @@ struct SharedEstimate {
 };
 static std::mutex g_est_mu;
 static std::unordered_map<uint64_t, SharedEstimate> g_est;
+static hipEvent_t g_base_event[64] = {};  // per device: the origin of focr_debug_phase_stamps (guarded by g_est_mu)
 
 void set_global_error(const std::string &s) {
     std::lock_guard<std::mutex> lk(g_err_mu);
@@ -252,6 +253,11 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         c->chunked_verify = getenv("FOCR_VERIFY_GLOBAL") == nullptr;
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->io_stream = c->stream;
+        {
+            std::lock_guard<std::mutex> lk(g_est_mu);
+            hipEvent_t &b = g_base_event[(unsigned)device % 64];
+            if (!b && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(b, c->stream);
+        }
         for (auto &ev : c->ev) FOCR_HIP(c, hipEventCreate(&ev));
         FOCR_HIP(c, hipMalloc(&c->d_counter, COUNTER_BYTES));
         FOCR_HIP(c, hipMemsetAsync(c->d_counter, 0, COUNTER_BYTES, c->stream));
@@ -326,6 +332,38 @@ int focr_ctx_set_column_drop(focr_ctx_t *c, int on) {
 int focr_debug_force_split(focr_ctx_t *c, int on) {
     if (!c) return FOCR_ERR_INVALID;
     c->force_split = on != 0;
+    return FOCR_OK;
+}
+
+// Diagnostic: where the phases of the context's last batch lie on the DEVICE's clock — milliseconds since a per-device base event
+// (recorded when the first context of the device is created): [0] statistics start, [1] statistics end, [2] scan kernels end,
+// [3] verify end, [4] ordering end, [5] process_hits start, [6] process_hits end, [7] start of the dominant scan launch, [8] its end.
+// What a kernel trace shows, without a profiler in the process (tools/r5_phase_dump: the two rhythms of DESIGN.md section 5).
+int focr_debug_phase_stamps(focr_ctx_t *c, double out[9]) {
+    if (!c || !out) return FOCR_ERR_INVALID;
+    if (int rc = finish_results(c)) return rc;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    hipEvent_t base = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_est_mu);
+        base = g_base_event[(unsigned)c->device % 64];
+    }
+    for (int i = 0; i < 9; i++) out[i] = -1.0;
+    if (!base) return FOCR_OK;
+    for (int i = 0; i < 7; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, base, c->ev[i]) == hipSuccess) out[i] = ms;
+        else (void)hipGetLastError();
+    }
+    size_t best = 0;
+    for (size_t i = 1; i < c->launches.size(); i++)
+        if (c->launches[i].alg_macs > c->launches[best].alg_macs) best = i;
+    if (!c->launches.empty() && c->launch_events.size() >= 2 * c->launches.size()) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, base, c->launch_events[2 * best]) == hipSuccess) out[7] = ms;
+        if (hipEventElapsedTime(&ms, base, c->launch_events[2 * best + 1]) == hipSuccess) out[8] = ms;
+        (void)hipGetLastError();
+    }
     return FOCR_OK;
 }
 

@@ -197,6 +197,13 @@ class Scanner:
         """Test hook (focr_debug_force_split): scan the batch in page sub-ranges as after a candidate overflow."""
         self._ck(self._lib.focr_debug_force_split(self._h, int(bool(on))))
 
+    def phase_stamps(self):
+        """focr_debug_phase_stamps: the last batch's phases on the device's clock (ms since the device's first context was created)."""
+        out = (C.c_double * 9)()
+        self._ck(self._lib.focr_debug_phase_stamps(self._h, out))
+        return dict(zip(("stats_start", "stats_end", "scan_end", "verify_end", "order_end", "post_start", "post_end", "scan_launch_start", "scan_launch_end"),
+                        [float(v) for v in out]))
+
     def set_tail_grid(self, num, den):
         """Test hook (focr_debug_set_tail_grid): the tail's persistent kernels on num / den times their workgroups (0, 0: as designed)."""
         self._ck(self._lib.focr_debug_set_tail_grid(self._h, int(num), int(den)))

@@ -419,6 +419,12 @@ int focr_debug_rnorm(focr_ctx_t *ctx, const uint32_t *s, const uint64_t *s2, con
  * without waiting for an overflow. */
 int focr_debug_force_split(focr_ctx_t *ctx, int on);
 
+/* Diagnostic: the phases of the context's last batch on the device's clock, in milliseconds since a per-device origin (the creation of
+ * the device's first context): [0] statistics start, [1] statistics end, [2] scan kernels end, [3] verify end, [4] ordering end,
+ * [5] process_hits start, [6] process_hits end, [7] start and [8] end of the scan launch with the most work; -1 where not available.
+ * What a kernel trace shows, without a profiler in the process. */
+int focr_debug_phase_stamps(focr_ctx_t *ctx, double out[9]);
+
 /* Test hook: launch the persistent kernels of the scan's tail (exact verify in its list and chunk forms, hit scatter, row sort) on
  * num / den times the workgroups they are designed for (0 / 0: as designed).  Results must be identical for every grid. */
 int focr_debug_set_tail_grid(focr_ctx_t *ctx, uint32_t num, uint32_t den);
