@@ -126,14 +126,6 @@ struct focr_ctx {
     // the lane's next batch is queued behind it — and reads results back on the lane's side stream (io_stream) for the same reason.
     bool owns_stream = true;
     hipStream_t io_stream = nullptr;    // device -> host / device -> device copies of finished results (== stream for a context of its own)
-    // The front of a batch — pages written into the context, the clear, the window statistics and the live-tile lists — depends on
-    // nothing the lane's previous batch does (that one works in another context): inside an executor it runs on the executor's
-    // FRONT stream (pre_stream, one per device: the fronts of all lanes follow each other in ticket order), ahead of the lane,
-    // and the lane's stream waits for it (ev_pre) in front of the scan kernel.  A context of its own: pre_stream == stream.
-    hipStream_t pre_stream = nullptr;
-    hipEvent_t ev_pre = nullptr;        // behind the front's last kernel on pre_stream
-    bool pre_dirty = false;             // pages were written on pre_stream since the lane's stream last waited for it
-    bool lane_busy = false;             // work of THIS context was queued on `stream` and nobody has waited for it yet (wait_batch): the next front waits for it on the device
     hipEvent_t batch_event = nullptr;   // set by the executor behind a batch's last kernel; consumed by the first wait (wait_batch, ctx.hip)
     bool tail_full_chip = false;        // the executor says nothing scans behind this batch (focr_pipe_end_of_stream / _announce_last): its tail may take every CU (rows2_verify)
     std::string err;
@@ -299,7 +291,7 @@ int fail(focr_ctx *ctx, int code, const std::string &msg);
 // launchers implemented in the .hip files
 int launch_scan_direct(focr_ctx *ctx, float threshold, int rust_formula);
 int launch_scan_mfma(focr_ctx *ctx, float threshold);
-int launch_clear(focr_ctx *c, const focr::ClearList &l, hipStream_t stream);  // zero every region of the list in one launch (scan_mfma.hip)
+int launch_clear(focr_ctx *c, const focr::ClearList &l);  // zero every region of the list in one launch (scan_mfma.hip)
 int exclusive_scan_u64(focr_ctx *c, const uint64_t *in, uint64_t *out, size_t n);
 int order_hits(focr_ctx *ctx);  // direct path: unordered hits in d_hit_keys / d_hit_sims -> everything below
 int finish_results(focr_ctx *c);  // wait for the stream once and read the result sizes of the last scan / process_hits
@@ -309,8 +301,7 @@ void bank_host_prepare(focr_ctx *c, const focr_template_t *templates, size_t n_t
 void layout_supers(focr_ctx *c);  // size classes -> super-classes, MFMA K layouts, bank offsets (host only)
 int pages_alt_ingest(focr_ctx *c, const void *d_luma, size_t n_pages, size_t r_w, size_t r_h, int invert, hipStream_t s);  // ctx.hip
 int pages_alt_swap(focr_ctx *c, size_t n_pages, size_t r_w, size_t r_h);
-void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream, hipStream_t pre_stream);  // ctx.hip: the context joins an executor's lane
-int join_front(focr_ctx *c);  // ctx.hip: the context's stream behind what its front stream holds (no-op for a context of its own)
+void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream);  // ctx.hip: the context joins an executor's lane
 bool post_queue_chars_copy(focr_ctx *c, void *dst, size_t dst_bytes);  // post.hip: the batch's characters to a device buffer, queued on the context's stream
 int wait_batch(focr_ctx *c);  // ctx.hip: until the context's queued work is done (its batch's event inside an executor, else its stream)
 int quantise_bank(focr_ctx *c, const uint8_t *dense, std::vector<int8_t> &qbank, std::vector<uint32_t> &tglobal, std::vector<uint32_t> &order_of);  // host only

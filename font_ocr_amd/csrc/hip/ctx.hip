@@ -253,8 +253,6 @@ int focr_ctx_create(int device, focr_ctx_t **out) {
         c->chunked_verify = getenv("FOCR_VERIFY_GLOBAL") == nullptr;
         FOCR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->io_stream = c->stream;
-        c->pre_stream = c->stream;
-        FOCR_HIP(c, hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
         {
             std::lock_guard<std::mutex> lk(g_est_mu);
             hipEvent_t &b = g_base_event[(unsigned)device % 64];
@@ -284,7 +282,6 @@ void focr_ctx_destroy(focr_ctx_t *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->pre_stream && c->pre_stream != c->stream) (void)hipStreamSynchronize(c->pre_stream);
     free_bank(c);
     free_results(c);
     free_dev(c->d_pages);
@@ -300,7 +297,6 @@ void focr_ctx_destroy(focr_ctx_t *c) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->launch_events)
         if (ev) (void)hipEventDestroy(ev);
-    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -539,7 +535,6 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
         return FOCR_OK;
     }
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->pre_stream != c->stream) FOCR_HIP(c, hipStreamSynchronize(c->pre_stream));
     free_dev(c->d_pages);
     free_dev(c->d_pages_i8);
     c->pages_capacity = 0;
@@ -557,9 +552,8 @@ int focr_pages_alloc(focr_ctx_t *c, size_t n_pages, size_t r_w, size_t r_h) {
         return fail(c, FOCR_ERR_NOMEM, "focr_pages_alloc: hipMalloc failed");
     }
     c->pages_capacity = n_pages;
-    FOCR_HIP(c, hipMemsetAsync(c->d_pages, 0, bytes, c->pre_stream));
-    FOCR_HIP(c, hipMemsetAsync(c->d_pages_i8, 0x80, bytes, c->pre_stream));  // paper (0) as int8
-    c->pre_dirty = true;
+    FOCR_HIP(c, hipMemsetAsync(c->d_pages, 0, bytes, c->stream));
+    FOCR_HIP(c, hipMemsetAsync(c->d_pages_i8, 0x80, bytes, c->stream));  // paper (0) as int8
     return FOCR_OK;
 }
 
@@ -567,7 +561,7 @@ static int ingest(focr_ctx *c, const uint8_t *d_src, size_t first, size_t count,
     const size_t n_rows = count * c->r_h;
     const unsigned blocks = (unsigned)std::min<size_t>(n_rows, (size_t)1 << 20);
     const int dwords = c->r_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0;
-    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(64), 0, c->pre_stream, d_src, c->d_pages, c->d_pages_i8, (uint32_t)c->r_w, (uint32_t)c->r_h, c->pitch,
+    hipLaunchKernelGGL(ingest_pages, dim3(blocks), dim3(64), 0, c->stream, d_src, c->d_pages, c->d_pages_i8, (uint32_t)c->r_w, (uint32_t)c->r_h, c->pitch,
                        c->rows_alloc, first, n_rows, invert, dwords);
     FOCR_HIP(c, hipGetLastError());
     c->scanned = c->processed = false;
@@ -656,18 +650,17 @@ int focr_pages_upload(focr_ctx_t *c, size_t first, size_t count, const uint8_t *
     const size_t chunk_pages = std::max<size_t>(1, (256u << 20) / page_bytes);
     size_t need = std::min(count, chunk_pages) * page_bytes;
     if (c->stage_bytes < need) {
-        FOCR_HIP(c, hipStreamSynchronize(c->pre_stream));
+        FOCR_HIP(c, hipStreamSynchronize(c->stream));
         free_dev(c->d_stage);
         FOCR_HIP(c, hipMalloc(&c->d_stage, need));
         c->stage_bytes = need;
     }
     for (size_t done = 0; done < count; done += chunk_pages) {
         size_t n = std::min(chunk_pages, count - done);
-        // (pages are written on the context's front stream — its own stream unless it belongs to an executor, common.h)
-        FOCR_HIP(c, hipMemcpyAsync(c->d_stage, luma + done * page_bytes, n * page_bytes, hipMemcpyHostToDevice, c->pre_stream));
+        FOCR_HIP(c, hipMemcpyAsync(c->d_stage, luma + done * page_bytes, n * page_bytes, hipMemcpyHostToDevice, c->stream));
         int rc = ingest(c, c->d_stage, first + done, n, invert);
         if (rc) return rc;
-        if (done + chunk_pages < count) FOCR_HIP(c, hipStreamSynchronize(c->pre_stream));  // staging buffer reuse
+        if (done + chunk_pages < count) FOCR_HIP(c, hipStreamSynchronize(c->stream));  // staging buffer reuse
     }
     return FOCR_OK;
 }
@@ -801,8 +794,6 @@ static int scan_now(focr_ctx *c) {
     c->sizes_pending = c->post_pending = false;
     for (auto &m : c->ms) m = 0.f;
     c->counters[3] = 0;
-    if (mode != FOCR_SCAN_MFMA)  // (the MFMA path runs its whole front on the front stream and joins behind it, launch_scan_mfma)
-        if (int r = join_front(c)) return r;
     auto run = [&](size_t p0, size_t np) -> int {  // the whole pipeline on pages [p0, p0 + np)
         c->sub_p0 = p0;
         c->sub_np = np;
@@ -838,42 +829,28 @@ void row_segments(const focr_ctx *c, uint32_t *seg_shift, uint32_t *n_seg);  // 
 
 // The context joins a lane of an executor (pipe.hip): it works on the lane's stream from now on (its own, idle, is destroyed) and reads
 // results back on the lane's side stream.
-void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream, hipStream_t pre_stream) {
+void ctx_share_stream(focr_ctx *c, hipStream_t lane_stream, hipStream_t io_stream) {
     (void)hipSetDevice(c->device);
     if (c->stream && c->owns_stream && c->stream != lane_stream) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
-    c->owns_stream = c->stream == lane_stream && c->owns_stream;  // (a lane's first context keeps the stream it brought)
+    c->owns_stream = false;
     c->stream = lane_stream;
     c->io_stream = io_stream ? io_stream : lane_stream;
-    c->pre_stream = pre_stream ? pre_stream : lane_stream;
-}
-
-// The context's stream behind everything its front stream holds for it (pages written there since the last join).
-int join_front(focr_ctx *c) {
-    if (c->pre_stream == c->stream || !c->pre_dirty) return FOCR_OK;
-    FOCR_HIP(c, hipEventRecord(c->ev_pre, c->pre_stream));
-    FOCR_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pre, 0));
-    c->pre_dirty = false;
-    return FOCR_OK;
 }
 
 // Until the work this context has queued is done.  Inside an executor that is the context's OWN batch (the event the executor
 // recorded behind its last kernel; consumed here) — the lane's stream already holds the next batch of another context; a context
 // with a stream of its own waits for the stream.
 int wait_batch(focr_ctx *c) {
-    // pages written on the front stream that no scan has joined yet (focr_pages_upload* then focr_sync: the caller may free its source)
-    if (c->pre_dirty && c->pre_stream != c->stream) FOCR_HIP(c, hipStreamSynchronize(c->pre_stream));
     if (c->batch_event) {
         hipEvent_t e = c->batch_event;
         c->batch_event = nullptr;
         FOCR_HIP(c, hipEventSynchronize(e));
-        c->lane_busy = false;
         return FOCR_OK;
     }
     FOCR_HIP(c, hipStreamSynchronize(c->stream));
-    c->lane_busy = false;
     return FOCR_OK;
 }
 

@@ -114,9 +114,6 @@ struct focr_pipe {
     bool next_is_last = false;  // focr_pipe_announce_last: the next submit ends the stream
     bool stop = false, fetch = false, trace = false;
     std::thread enq;
-    // the fronts of the batches of all lanes (pages into the context, clear, window statistics, live-tile lists: common.h,
-    // focr_ctx::pre_stream), one behind the other in ticket order, ahead of the lanes: a lane's stream holds scan + tail only
-    hipStream_t front_stream = nullptr;
     // completion events by ticket (ring: a ticket's event is recorded again DONE_RING tickets later, long after it has been retired):
     // the device-side interval between the last kernels of consecutive tickets comes from two neighbours of the ring
     static constexpr unsigned DONE_RING = 128;
@@ -194,9 +191,7 @@ static void enqueue_main(focr_pipe *P) {
                 if (rc != FOCR_OK) c->err = focr_last_error_global();
             }
             if (rc == FOCR_OK && (prefetched || alt_free)) {  // the pages are in the alternate set (or on their way): behind one event, the sets change places
-                // (the batch's front — statistics, live-tile lists — reads the pages first, on the executor's front stream)
-                hipError_t e = hipStreamWaitEvent(c->pre_stream, S->ev_prefetch, 0);
-                if (e == hipSuccess && c->pre_stream != c->stream) e = hipStreamWaitEvent(c->stream, S->ev_prefetch, 0);
+                hipError_t e = hipStreamWaitEvent(c->stream, S->ev_prefetch, 0);
                 if (e != hipSuccess) rc = fail(c, FOCR_ERR_NO_DEVICE, std::string("focr_pipe: prefetch wait failed: ") + hipGetErrorString(e));
                 if (rc == FOCR_OK) rc = pages_alt_swap(c, job.n_pages, job.r_w, job.r_h);
             } else if (rc == FOCR_OK) {  // the alternate set belongs to a later batch: upload on the lane's own stream
@@ -352,12 +347,6 @@ int focr_pipe_create2(int device, unsigned n_lanes, unsigned depth, focr_pipe_t 
         }
         if (bad != FOCR_OK) return bail(bad);
     }
-    if (!getenv("FOCR_PIPE_NO_FRONT")) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&p->front_stream, hipStreamNonBlocking, getenv("FOCR_FRONT_LOW") ? least : 0) != hipSuccess)
-            return bail(fail(nullptr, FOCR_ERR_NO_DEVICE, "focr_pipe_create: hipStreamCreate failed"));
-    }
     for (unsigned i = 0; i < n_lanes * depth; i++) {
         PipeSlot *S = p->slots[i];
         if (i < n_lanes) {  // the lane: its stream is the first context's; a copy stream and a side stream of its own
@@ -366,8 +355,10 @@ int focr_pipe_create2(int device, unsigned n_lanes, unsigned depth, focr_pipe_t 
             p->lanes.push_back(L);
             if (hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&L->io_stream, hipStreamNonBlocking) != hipSuccess)
                 return bail(fail(nullptr, FOCR_ERR_NO_DEVICE, "focr_pipe_create: hipStreamCreate failed"));
+            S->ctx->io_stream = L->io_stream;
+        } else {
+            ctx_share_stream(S->ctx, p->lanes[S->lane]->stream, p->lanes[S->lane]->io_stream);
         }
-        ctx_share_stream(S->ctx, p->lanes[S->lane]->stream, p->lanes[S->lane]->io_stream, p->front_stream);
         if (hipEventCreateWithFlags(&S->ev_prefetch, hipEventDisableTiming) != hipSuccess)
             return bail(fail(nullptr, FOCR_ERR_NO_DEVICE, "focr_pipe_create: hipEventCreate failed"));
         // several lanes: the persistent scan kernel takes seven eighths of the CUs and leaves the rest to the other lanes' small
@@ -416,7 +407,6 @@ void focr_pipe_destroy(focr_pipe_t *p) {
         }
     }
     (void)hipSetDevice(p->device);
-    if (p->front_stream) (void)hipStreamSynchronize(p->front_stream);
     for (PipeLane *L : p->lanes) {
         if (L->stream) (void)hipStreamSynchronize(L->stream);
         if (L->copy_stream) (void)hipStreamSynchronize(L->copy_stream);
@@ -432,7 +422,6 @@ void focr_pipe_destroy(focr_pipe_t *p) {
     }
     for (hipEvent_t e : p->done_ring)
         if (e) (void)hipEventDestroy(e);
-    if (p->front_stream) (void)hipStreamDestroy(p->front_stream);
     for (PipeLane *L : p->lanes) {
         if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
         if (L->io_stream) (void)hipStreamDestroy(L->io_stream);

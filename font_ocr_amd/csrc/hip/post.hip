@@ -225,7 +225,7 @@ int focr_process_hits(focr_ctx_t *c, float anchor_threshold, int32_t overlap) {
         ClearList clear{};  // one launch instead of two memsets (common.h)
         if (!clear.add(keep_row, n_rows_total)) return fail(c, FOCR_ERR_INVALID, "focr_process_hits: clear list full or region too large");
         if (!clear.add(packed, (n_rows_total + 1) * 8)) return fail(c, FOCR_ERR_INVALID, "focr_process_hits: clear list full or region too large");
-        if (int rc = launch_clear(c, clear, c->stream)) return rc;
+        if (int rc = launch_clear(c, clear)) return rc;
     }
     const unsigned nb = (unsigned)((ub + 255) / 256);
     if (ub)

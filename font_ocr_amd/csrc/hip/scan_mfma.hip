@@ -70,11 +70,11 @@ __global__ __launch_bounds__(256) void clear_kernel(const ClearList l) {
         for (uint32_t i = tid; i < l.n8[r]; i += step) p[i] = 0;
     }
 }
-int launch_clear(focr_ctx *c, const ClearList &l, hipStream_t stream) {
+int launch_clear(focr_ctx *c, const ClearList &l) {
     size_t words = 0;
     for (uint32_t r = 0; r < l.n; r++) words += l.n8[r];
     if (!words) return FOCR_OK;
-    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)std::min<size_t>(1024, (words + 1023) / 1024)), dim3(256), 0, stream, l);
+    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)std::min<size_t>(1024, (words + 1023) / 1024)), dim3(256), 0, c->stream, l);
     FOCR_HIP(c, hipGetLastError());
     return FOCR_OK;
 }
@@ -608,7 +608,7 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
     if (pair >= 0) B = StatsOut{plane_params(c, (size_t)pair, thr_d), out_pair};
     const bool drop = sc.keep_w != sc.n_w, small = sc.n_w * sc.n_h <= 256;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->pre_stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+        hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                            (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows);
     };
 #define STATS_CASE(NDW)                                                                          \
@@ -696,42 +696,14 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         if (use_rows && (rc = rows2_begin(c, clear))) return rc;  // hits-first row tail: verify in flush order, only hits are bucketed and sorted (rows.hip)
         // legacy tail, estimated sizes: unused candidate slots hold the largest key so that the radix sort leaves them at the end
         if (c->estimated && !use_rows) FOCR_HIP(c, hipMemsetAsync(c->d_cand, 0xff, c->ub_cand * 8, c->stream));
-        // From here to the live-tile lists the batch runs on the context's FRONT stream (common.h: pre_stream — the context's own
-        // stream unless it belongs to an executor, whose lanes' fronts run ahead of the lanes on one stream per device)
-        hipStream_t front = c->pre_stream;
-        if (front != c->stream && c->lane_busy) {
-            // an earlier batch of THIS context may still be running on its stream (two scans with no wait in between — an executor
-            // completes a context's batch before it queues the next): the clear below must not run under it
-            FOCR_HIP(c, hipEventRecord(c->ev_pre, c->stream));
-            FOCR_HIP(c, hipStreamWaitEvent(front, c->ev_pre, 0));
-        }
-        if (front != c->stream) {
-            // ... and just in time: the front of the scan that will take turn n starts when the scan of turn n - LEAD + 1 does (the
-            // end of turn n - LEAD, scan_turns below), so that it shares the CUs the scan kernel leaves free with the tails of the
-            // batches in front of it for one scan's time, not with all of them for as long as the executor's queue is deep
-            static const unsigned lead = getenv("FOCR_FRONT_LEAD") ? (unsigned)atoi(getenv("FOCR_FRONT_LEAD")) : 2u;
-            ScanTurns &tn = scan_turns[(unsigned)c->device % 64];
-            std::lock_guard<std::mutex> turn(tn.mu);
-            if (lead >= 1 && lead <= 6 && tn.init && tn.n >= lead) FOCR_HIP(c, hipStreamWaitEvent(front, tn.ev[(tn.n - lead) % 8], 0));
-        }
-        FOCR_HIP(c, hipEventRecord(c->ev[0], front));
+        FOCR_HIP(c, hipEventRecord(c->ev[0], c->stream));
         // `sim > +inf` is never true (NaN thresholds arrive here as +inf, focr_scan): no statistics, no scan, zero candidates
         // (kappa would be inf - inf = NaN and every window of every live tile a candidate for verify to reject)
         const bool nothing = !(thr_d < (double)INFINITY);
         if (nothing) {
-            if ((rc = launch_clear(c, clear, front))) return rc;
-            FOCR_HIP(c, hipEventRecord(c->ev[1], front));
+            if ((rc = launch_clear(c, clear))) return rc;
+            FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
         }
-        // the lane's stream continues behind the front
-        auto join = [&]() -> int {
-            c->pre_dirty = false;
-            c->lane_busy = true;
-            if (front == c->stream) return FOCR_OK;
-            FOCR_HIP(c, hipEventRecord(c->ev_pre, front));
-            FOCR_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pre, 0));
-            return FOCR_OK;
-        };
-        if (nothing && (rc = join())) return rc;
         if (!nothing) {
         // 1. statistics + live-tile work lists, per super-class (classes that share one scan pass)
         size_t tiles_total = 0;
@@ -769,11 +741,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 for (hipEvent_t &e : st.ev) FOCR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 st.init = true;
             }
-            if (st.n) FOCR_HIP(c, hipStreamWaitEvent(front, st.ev[(st.n - 1) % 8], 0));
+            if (st.n) FOCR_HIP(c, hipStreamWaitEvent(c->stream, st.ev[(st.n - 1) % 8], 0));
             // (the event of THIS batch's statistics is recorded below, under the same lock order: reserve its place now)
             c->stats_turn = st.n++;
         }
-        if ((rc = launch_clear(c, clear, front))) return rc;
+        if ((rc = launch_clear(c, clear))) return rc;
         // which super-classes take the plane path (scan_mfma2s_kernel), and their threshold planes
         const size_t plane = c->sub_np * (size_t)Lrows * Lpitch;  // int16 values per plane
         std::vector<int> two(c->supers.size(), 0);
@@ -792,7 +764,6 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
         }
         if (c->planes_bytes < plane_vals * 2) {
             FOCR_HIP(c, hipStreamSynchronize(c->stream));
-            FOCR_HIP(c, hipStreamSynchronize(front));
             if (c->d_planes) (void)hipFree(c->d_planes);
             c->d_planes = nullptr;
             c->planes_bytes = 0;
@@ -834,16 +805,15 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                 if (pair >= 0) done[pv] = 1;
             }
             const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->sub_np);
-            hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, front, live + su.live_offset, nt, su.mtx,
+            hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
                                su.n_rows, 1u, live_list + su.live_offset, c->d_counter + 8 + si);
             FOCR_HIP(c, hipGetLastError());
         }
-        FOCR_HIP(c, hipEventRecord(c->ev[1], front));
+        FOCR_HIP(c, hipEventRecord(c->ev[1], c->stream));
         if (stats_chain) {
             std::lock_guard<std::mutex> turn(st.mu);
-            FOCR_HIP(c, hipEventRecord(st.ev[c->stats_turn % 8], front));
+            FOCR_HIP(c, hipEventRecord(st.ev[c->stats_turn % 8], c->stream));
         }
-        if ((rc = join())) return rc;
         // 2. MFMA prefilter: one launch per (super-class, bank chunk that fits the LDS budget).
         // With several contexts in flight on one GPU the persistent scan kernels take turns: each context's launches
         // wait (on the device, hipStreamWaitEvent) for the previous context's to finish.  Two of them sharing the
