@@ -915,6 +915,39 @@ def test_pipeline_two_threads_and_close_with_batches_outstanding(bank_x2):
         pipe.close()  # finishes them first
 
 
+def test_direct_scans_on_an_executor_context_back_to_back(bank_x2):
+    """A context of an executor may also be driven directly (bench.py's isolated-kernel leg does: scan + process_hits several times
+    with no wait in between, then reads the last result): every scan's front — the clear, the statistics — must stay behind the
+    previous scan's tail in the context's buffers.  (Round 5's front-stream experiment ran them on another stream and faulted
+    exactly here.)  Estimated sizes: the first scan is exact, the following ones run on its sizes without a host wait."""
+    from font_ocr_amd.searcher import Pipeline
+
+    pages = np.stack([synth_page(bank_x2, SYNTH_SEED_BASE + 3100 + p, 300, 110) for p in range(4)])
+    with Scanner(0) as sc:
+        sc.set_bank(bank_x2)
+        sc.set_pages(pages)
+        sc.scan(0.8, 1024, SCAN_MFMA)
+        sc.process_hits(0.95, 5)
+        want = (sc.matches()[1].tobytes(), sc.lines_flat().tobytes())
+    pipe = Pipeline(0, 3)
+    try:
+        pipe.set_bank(bank_x2)
+        t = pipe.submit(pages, 0.8)  # through the executor once: the context's pages are resident
+        c_ = pipe.wait(t)
+        assert (c_.matches()[1].tobytes(), c_.lines_flat().tobytes()) == want
+        pipe.release(t)
+        for _ in range(6):  # directly, no wait between the calls
+            c_.scan(0.8, 1024, SCAN_MFMA)
+            c_.process_hits(0.95, 5)
+        assert (c_.matches()[1].tobytes(), c_.lines_flat().tobytes()) == want
+        t = pipe.submit(pages, 0.8)  # and through the executor again
+        c2 = pipe.wait(t)
+        assert (c2.matches()[1].tobytes(), c2.lines_flat().tobytes()) == want
+        pipe.release(t)
+    finally:
+        pipe.close()
+
+
 def test_pipeline_chars_out_with_estimated_and_redone_batches(bank_x2):
     """chars_out of focr_pipe_submit: the characters' copy into the caller's device buffer is queued behind process_hits on the lane's
     stream (a kernel that reads their number on the device) — also when the batch runs on size estimates, and a batch whose estimates
