@@ -121,6 +121,8 @@ HIP_SYMBOLS = {
     "focr_debug_force_split": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_debug_set_tail_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "focr_debug_phase_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "focr_debug_set_stats_form": (C.c_int, [C.c_void_p, C.c_int]),
+    "focr_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "focr_ctx_set_size_estimates": (C.c_int, [C.c_void_p, C.c_int]),
     "focr_size_estimate_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "focr_ctx_set_column_drop": (C.c_int, [C.c_void_p, C.c_int]),

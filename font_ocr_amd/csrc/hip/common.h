@@ -164,6 +164,7 @@ struct focr_ctx {
     int scan_mode = 0;
     int32_t post_overlap = 0;
     bool force_split = false;                   // tests: take scan_split without waiting for an overflow (focr_debug_force_split)
+    int dbg_stats_form = 0;  // tests / A-B: 1 = the LDS-tiled statistics kernel for every class (focr_debug_set_stats_form; 0: the register form where it applies)
     uint32_t dbg_grid_num = 0, dbg_grid_den = 0;  // tests: the tail's persistent kernels on num / den times their workgroups (focr_debug_set_tail_grid; 0: as designed)
     int prefilter = 0;                          // FOCR_PREFILTER_*: auto / plane kernel / legacy kernel (focr_ctx_set_prefilter)
     uint16_t *d_planes = nullptr;               // threshold planes, int16: [super-class][value][page][Lrows][Lpitch] (mfma_common.h)

@@ -374,6 +374,23 @@ int focr_debug_set_tail_grid(focr_ctx_t *c, uint32_t num, uint32_t den) {
     return FOCR_OK;
 }
 
+int focr_debug_set_stats_form(focr_ctx_t *c, int form) {
+    if (!c || form < 0 || form > 1) return FOCR_ERR_INVALID;
+    c->dbg_stats_form = form;
+    return FOCR_OK;
+}
+
+int focr_debug_planes(focr_ctx_t *c, uint16_t *out, size_t capacity, size_t *n_values) {
+    if (!c || !n_values) return FOCR_ERR_INVALID;
+    FOCR_HIP(c, hipSetDevice(c->device));
+    if (int rc = focr_sync(c)) return rc;
+    *n_values = c->planes_bytes / 2;
+    if (!out) return FOCR_OK;
+    if (capacity < *n_values) return fail(c, FOCR_ERR_INVALID, "focr_debug_planes: buffer too small");
+    if (*n_values) FOCR_HIP(c, hipMemcpy(out, c->d_planes, *n_values * 2, hipMemcpyDeviceToHost));
+    return FOCR_OK;
+}
+
 int focr_sync(focr_ctx_t *c) {
     if (!c) return FOCR_ERR_INVALID;
     FOCR_HIP(c, hipSetDevice(c->device));

@@ -251,6 +251,141 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     }
 }
 
+// The same statistics for a kept width of 8 columns (BASELINE configs[1] and [2]: 8-wide classes and 9-wide ones with their last column
+// dropped), VERTICAL sums first and no LDS: a lane owns four neighbouring columns (one dword of every page row), slides the
+// n_h-row sums of its four columns down S8_ROWS window rows — C1 = sum of bytes, C2 = sum of squares, from the row that enters and
+// the row that leaves: d = in - out, C1 += d, C2 += d * (in + out) — and the horizontal 8-sums come out of the lanes' registers:
+// window x = 4L + i covers columns 4L + i .. 4L + i + 7 = the rest of lane L's dword, all of lane L + 1's, the first i columns
+// of lane L + 2's; the dropped ninth column is column i of lane L + 2.  Two row sums from lane L + 1 and eight column sums from
+// lane L + 2 per row (ds_bpermute), no tile staging, no barrier, four plane values per 8-byte store.  A wave is a strip of 240
+// window columns (lanes 60..63 only feed their neighbours) x S8_ROWS rows of one page; a row of the strip whose 8 + 256 columns
+// are blank over the n_h rows (every C2 zero) stores "never" without the arithmetic.  Results: the same exact integers s, s2, q1,
+// q2 as stats_kernel, then the same code — plane for plane identical (tests/test_gpu_parity.py: the planes of both kernels, and every parity test).
+constexpr uint32_t S8_COLS = 240, S8_ROWS = 16;  // (8 / 24 / 32 rows per wave: 133 / 130 / 141 us against 130 before the rows were prefetched; 16 and 24 level after)
+template <bool SMALLN, bool DROP, bool PAIR>
+__global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
+                                                     uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
+                                                     uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
+                                                     uint32_t n_tasks) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (task >= n_tasks) return;  // wave-uniform; no barrier anywhere below
+    const uint32_t per_page = strips_x * bands_y, page = task / per_page, in_page = task - page * per_page;
+    const uint32_t x0 = (in_page % strips_x) * S8_COLS, y0 = (in_page / strips_x) * S8_ROWS;
+    const uint32_t xl = x0 + 4 * lane;  // the lane's first column = its first window
+    // lanes right of the row read its zero padding (>= 64 zero bytes right of every row, focr_pages_alloc)
+    const uint32_t off = xl + 4 <= pitch ? xl : pitch - 4;
+    const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
+    auto load_row = [&](uint32_t y) -> uint32_t {  // wave-uniform row test (pages end with >= 48 zero rows: never taken at the sizes the MFMA path covers)
+        return y < rows_alloc ? *reinterpret_cast<const uint32_t *>(pg + (size_t)y * pitch + off) : 0u;
+    };
+    uint32_t c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < n_h; j += 8) {  // the first window row's sums: eight page rows per round trip to memory
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = load_row(y0 + j + i);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (j + i >= n_h) v[i] = 0;  // wave-uniform
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t b = (v[i] >> (8 * m)) & 0xffu;
+                c1[m] += b;
+                c2[m] += __umul24(b, b);
+            }
+        }
+    }
+    const int a1 = (int)(lane + 1 < 64 ? lane + 1 : 63) * 4, a2 = (int)(lane + 2 < 64 ? lane + 2 : 63) * 4;  // ds_bpermute addresses
+    const uint32_t n = n_w * n_h, n_k = (n_w - 1) * n_h;
+    const bool store_lane = lane < S8_COLS / 4 && xl < Lpitch;
+    const bool mark_lane = (lane & 3) == 0 && (xl >> 4) < mtx;
+    char *outA = reinterpret_cast<char *>(A.out), *outB = reinterpret_cast<char *>(B.out);
+#pragma unroll 2
+    for (uint32_t k = 0; k < S8_ROWS; k++) {
+        const uint32_t y = y0 + k;
+        if (y >= Lrows) break;  // wave-uniform
+        // the rows that enter and leave when the window slides down: asked for now, used behind this row's arithmetic
+        const uint32_t vi = load_row(y + n_h), vo = load_row(y);
+        const uint32_t entry = ((page * Lrows + y) * Lpitch + xl) * 2u;  // byte offset of the lane's four values in a plane (a pass's planes span < 4 GiB)
+        const bool y_ok = y >= 1 && y + n_h <= r_h;
+        const uint32_t nzc = c2[0] | c2[1] | c2[2] | c2[3];
+        if (__builtin_amdgcn_ballot_w64(nzc != 0) == 0 || !y_ok) {
+            // nothing but paper under the strip's windows of this row (or a row the reference never searches): "never", no marks
+            if (store_lane) {
+                const uint32_t nv = (uint32_t)(uint16_t)PLANE_NEVER * 0x10001u;
+                *reinterpret_cast<uint2 *>(outA + entry) = uint2{nv, nv};
+                if (PAIR) *reinterpret_cast<uint2 *>(outB + entry) = uint2{nv, nv};
+            }
+        } else {
+            const uint32_t R1 = c1[0] + c1[1] + c1[2] + c1[3], R2 = c2[0] + c2[1] + c2[2] + c2[3];
+            uint32_t s_k = R1 + (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)R1), s2_k = R2 + (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)R2);
+            uint32_t e1[4], e2[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                e1[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)c1[m]);
+                e2[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)c2[m]);
+            }
+            int16_t va[4], vb[4];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = xl + i, q1 = e1[i], q2 = e2[i];
+                const bool x_ok = x >= 1 && x + n_w <= r_w, xk_ok = x >= 1 && x + n_w - 1 <= r_w;
+                const uint32_t s = DROP ? s_k + q1 : s_k, s2 = DROP ? s2_k + q2 : s2_k;  // the full box
+                bool nz;
+                float Vf;
+                if (SMALLN) {
+                    const uint32_t V = __umul24(n, s2) - __umul24(s, s);
+                    nz = V != 0;
+                    Vf = (float)V;
+                } else {
+                    const uint64_t V = (uint64_t)n * s2 - (uint64_t)s * s;
+                    nz = V != 0;
+                    Vf = (float)V;
+                }
+                const bool emit = x_ok && nz;
+                any |= emit;
+                const float La = DROP ? threshold_f32(A.p, Vf, dropped_column_W_upper(n_k, n_h, s_k, q1, q2)) : threshold_f32_nodrop(A.p, Vf);
+                va[i] = emit ? plane_value(A.p, La) : PLANE_NEVER;
+                if (PAIR) {
+                    bool nzk;
+                    float Vkf;
+                    if (SMALLN) {
+                        const uint32_t Vk = __umul24(n_k, s2_k) - __umul24(s_k, s_k);
+                        nzk = Vk != 0;
+                        Vkf = (float)Vk;
+                    } else {
+                        const uint64_t Vk = (uint64_t)n_k * s2_k - (uint64_t)s_k * s_k;
+                        nzk = Vk != 0;
+                        Vkf = (float)Vk;
+                    }
+                    const bool emit_k = xk_ok && nzk;
+                    any |= emit_k;
+                    vb[i] = emit_k ? plane_value(B.p, threshold_f32_nodrop(B.p, Vkf)) : PLANE_NEVER;
+                }
+                s_k += e1[i] - c1[i];  // one column to the right
+                s2_k += e2[i] - c2[i];
+            }
+            if (store_lane) {
+                *reinterpret_cast<uint2 *>(outA + entry) = uint2{(uint32_t)(uint16_t)va[0] | ((uint32_t)(uint16_t)va[1] << 16), (uint32_t)(uint16_t)va[2] | ((uint32_t)(uint16_t)va[3] << 16)};
+                if (PAIR) *reinterpret_cast<uint2 *>(outB + entry) = uint2{(uint32_t)(uint16_t)vb[0] | ((uint32_t)(uint16_t)vb[1] << 16), (uint32_t)(uint16_t)vb[2] | ((uint32_t)(uint16_t)vb[3] << 16)};
+            }
+            // M-tile marks: an M-tile is the 16 windows of four lanes (x0 is a multiple of 16)
+            const uint64_t lm = __builtin_amdgcn_ballot_w64(any && store_lane);
+            if (mark_lane && ((lm >> lane) & 0xfu) && y <= n_rows) live[(page * n_rows + y - 1) * mtx + (xl >> 4)] = 1;
+        }
+        {  // slide down one row
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t bi = (vi >> (8 * m)) & 0xffu, bo = (vo >> (8 * m)) & 0xffu;
+                const int d = (int)bi - (int)bo;
+                c1[m] += (uint32_t)d;
+                c2[m] += (uint32_t)__mul24(d, (int)(bi + bo));
+            }
+        }
+    }
+}
+
 // Live M-tiles -> packed work list (page << 32 | row << 12 | col).  A block compacts 4096 consecutive tiles
 // (16 per thread) with one global atomic, so the shared counter sees ~1 atomic per 4096 tiles.  The order of the
 // list does not matter for the results (every M-tile is independent; hits are sorted later).
@@ -607,6 +742,23 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
     StatsOut A{plane_params(c, k, thr_d), out}, B{};
     if (pair >= 0) B = StatsOut{plane_params(c, (size_t)pair, thr_d), out_pair};
     const bool drop = sc.keep_w != sc.n_w, small = sc.n_w * sc.n_h <= 256;
+    static const bool no_s8 = getenv("FOCR_NO_STATS8") != nullptr;  // A/B and the planes' equality test: the LDS-tiled kernel for every class
+    if (OUT == 1 && sc.keep_w == 8 && !no_s8 && c->dbg_stats_form == 0) {  // kept width 8: the register form (stats8_kernel)
+        const uint32_t cols = std::min<uint32_t>(Lpitch, 16 * mtx), rows_n = std::min<uint32_t>(Lrows, n_rows + 1);
+        const uint32_t strips_x = (cols + S8_COLS - 1) / S8_COLS, bands_y = (rows_n + S8_ROWS - 1) / S8_ROWS;
+        const uint64_t n_tasks = (uint64_t)strips_x * bands_y * c->sub_np;
+        if (n_tasks >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
+        auto launch8 = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+                               (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows, strips_x, bands_y,
+                               (uint32_t)n_tasks);
+        };
+        if (pair >= 0) small ? launch8(stats8_kernel<true, true, true>) : launch8(stats8_kernel<false, true, true>);
+        else if (drop) small ? launch8(stats8_kernel<true, true, false>) : launch8(stats8_kernel<false, true, false>);
+        else small ? launch8(stats8_kernel<true, false, false>) : launch8(stats8_kernel<false, false, false>);
+        FOCR_HIP(c, hipGetLastError());
+        return FOCR_OK;
+    }
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(256), stats_lds_bytes(sc.n_h), c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                            (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows);

@@ -208,6 +208,19 @@ class Scanner:
         """Test hook (focr_debug_set_tail_grid): the tail's persistent kernels on num / den times their workgroups (0, 0: as designed)."""
         self._ck(self._lib.focr_debug_set_tail_grid(self._h, int(num), int(den)))
 
+    def set_stats_form(self, form):
+        """Test hook (focr_debug_set_stats_form): 1 = the LDS-tiled statistics kernel for every class, 0 = the register form where it applies."""
+        self._ck(self._lib.focr_debug_set_stats_form(self._h, int(form)))
+
+    def planes(self):
+        """Test hook (focr_debug_planes): the int16 threshold planes of the last MFMA scan, flat."""
+        n = C.c_size_t(0)
+        self._ck(self._lib.focr_debug_planes(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.int16)
+        if n.value:
+            self._ck(self._lib.focr_debug_planes(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def set_scan_cus(self, max_cus):
         """Upper bound on the CUs the persistent scan kernel occupies (0 = all)."""
         self._ck(self._lib.focr_ctx_set_scan_cus(self._h, int(max_cus)))

@@ -429,6 +429,13 @@ int focr_debug_phase_stamps(focr_ctx_t *ctx, double out[9]);
  * num / den times the workgroups they are designed for (0 / 0: as designed).  Results must be identical for every grid. */
 int focr_debug_set_tail_grid(focr_ctx_t *ctx, uint32_t num, uint32_t den);
 
+/* Test hooks for the window statistics: form 1 = the LDS-tiled kernel for every size class (0: the register form for classes whose
+ * kept width is 8 px, scan_mfma.hip); focr_debug_planes copies the int16 threshold planes of the context's last MFMA scan to the
+ * host ([value][page][Lrows][Lpitch] per pass, Lpitch = (r_w + 63) / 64 * 64 + 64, Lrows = (r_h + 7) / 8 * 8 + 8; out = NULL: only
+ * their number).  Both forms must write the same planes wherever the scan kernel reads them. */
+int focr_debug_set_stats_form(focr_ctx_t *ctx, int form);
+int focr_debug_planes(focr_ctx_t *ctx, uint16_t *out, size_t capacity, size_t *n_values);
+
 /* Host model of the MFMA prefilter's bound (no device needed; used by the CPU tests, tests/test_prefilter_host.py): builds
  * the quantised bank exactly as focr_bank_upload does and evaluates, for n_windows caller-supplied ink-high patches of
  * frame_w x frame_h bytes (row-major; every template must fit the frame, its window is the frame's top-left n_w x n_h

@@ -108,6 +108,46 @@ def test_threshold_plane_values_device_equals_host(scanner):
         assert host.min() >= -32767  # -32768 is the "never" value: a threshold never maps to it
 
 
+@pytest.mark.parametrize("shapes", [[(9, 15), (8, 15)], [(9, 15)], [(8, 15)], [(8, 32), (9, 32)], [(8, 4), (9, 7)]],
+                         ids=["pair", "drop", "plain", "tall32", "short"])
+@pytest.mark.parametrize("geom", [(3, 301, 111), (2, 608, 720), (5, 64, 40), (1, 1021, 67)], ids=["301x111", "608x720", "64x40", "1021x67"])
+def test_statistics_register_form_writes_the_same_planes(shapes, geom):
+    """Classes whose kept width is 8 px take the register form of the window statistics (stats8_kernel: vertical sums first, a lane
+    per four columns, no LDS); every other class the LDS-tiled kernel.  Both must leave the same int16 threshold planes wherever the
+    scan kernel reads them (x < 16 * mtx, y <= n_rows) and the same live M-tiles — hence the same candidates, hits and lines —
+    for every geometry: widths that are no multiple of 4, strips that end inside / beyond the row's padding, pages lower than a band."""
+    np_, r_w, r_h = geom
+    rng = np.random.default_rng(1000 * r_w + r_h + len(shapes))
+    bank = _random_bank(rng, shapes, 5)
+    pages = rng.integers(0, 256, (np_, r_h, r_w), dtype=np.uint8)
+    pages[rng.random(pages.shape) < 0.55] = 0  # paper
+    pages[0, : r_h // 3] = 0                   # a blank band: the "nothing but paper" row path
+    if r_w > 300:
+        pages[:, :, 250:290] = 0               # and blank columns across a strip boundary
+    thr = 0.35
+    got = []
+    with Scanner(0) as sc:
+        sc.set_bank(bank)
+        sc.set_pages(pages)
+        for form in (1, 0):
+            sc.set_stats_form(form)
+            sc.scan(thr, 1024, SCAN_MFMA)
+            sc.process_hits(0.6, 5)
+            got.append((sc.planes().copy(), sc.matches()[0].tobytes(), sc.matches()[1].tobytes(), sc.lines_flat().tobytes(), dict(sc.counters())))
+    (p1, c1, m1, l1, k1), (p0, c0, m0, l0, k0) = got
+    assert (c1, m1, l1) == (c0, m0, l0)
+    assert k1["candidates"] == k0["candidates"], (k1, k0)
+    min_w, min_h = min(w for w, h in shapes), min(h for w, h in shapes)
+    mtx, n_rows = (r_w - min_w + 1 + 15) // 16, r_h - min_h
+    Lpitch, Lrows = (r_w + 63) // 64 * 64 + 64, (r_h + 7) // 8 * 8 + 8
+    nv = 1 if len(shapes) <= 1 else 2
+    assert p1.size == p0.size and p1.size >= nv * np_ * Lrows * Lpitch
+    a = p1[: nv * np_ * Lrows * Lpitch].reshape(nv, np_, Lrows, Lpitch)[:, :, : n_rows + 1, : min(16 * mtx, Lpitch)]
+    b = p0[: nv * np_ * Lrows * Lpitch].reshape(nv, np_, Lrows, Lpitch)[:, :, : n_rows + 1, : min(16 * mtx, Lpitch)]
+    assert np.array_equal(a, b), np.argwhere(a != b)[:8]
+    assert (a != -32768).any()  # some windows can emit: the comparison is not of two empty planes
+
+
 def test_compat_symbols_on_golden_vectors(kernel_cases):
     """ncc_8_u8 / ncc_16_u8 (the reference's FFI names) == the reference kernel's committed outputs."""
     for name, c in kernel_cases.items():
