@@ -262,17 +262,26 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
 // are blank over the n_h rows (every C2 zero) stores "never" without the arithmetic.  Results: the same exact integers s, s2, q1,
 // q2 as stats_kernel, then the same code — plane for plane identical (tests/test_gpu_parity.py: the planes of both kernels, and every parity test).
 constexpr uint32_t S8_COLS = 240, S8_ROWS = 16;  // (8 / 24 / 32 rows per wave: 133 / 130 / 141 us against 130 before the rows were prefetched; 16 and 24 level after)
-template <bool SMALLN, bool DROP, bool PAIR>
+//   APPEND: the launch is the only statistics launch of its scan pass (BASELINE configs[1]: both classes in one PAIR launch), so a
+//   marked M-tile is final: instead of a mark byte for compact_live_tiles the wave remembers its marks (16 rows x 15 M-tiles: one
+//   bit per row in each quad's first lane) and appends them to the pass's work list itself, in row-major order, behind ONE atomic
+//   per workgroup — no mark bytes, no compaction launch between the statistics and the scan kernel.
+template <bool SMALLN, bool DROP, bool PAIR, bool APPEND>
 __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
                                                      uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
                                                      uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
-                                                     uint32_t n_tasks) {
-    const uint32_t lane = threadIdx.x & 63;
+                                                     uint32_t n_tasks, uint64_t *__restrict__ list, uint32_t *__restrict__ list_count) {
+    __shared__ uint32_t wg_cnt[4];
+    __shared__ uint32_t wg_base;
+    const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (task >= n_tasks) return;  // wave-uniform; no barrier anywhere below
-    const uint32_t per_page = strips_x * bands_y, page = task / per_page, in_page = task - page * per_page;
-    const uint32_t x0 = (in_page % strips_x) * S8_COLS, y0 = (in_page / strips_x) * S8_ROWS;
-    const uint32_t xl = x0 + 4 * lane;  // the lane's first column = its first window
+    uint32_t mymask = 0, page = 0, y0 = 0, xl = 0;  // APPEND: bit k = the M-tile of this quad is live in window row y0 + k
+    if (task < n_tasks) {  // wave-uniform (without APPEND there is no barrier below and the wave could simply leave)
+    const uint32_t per_page = strips_x * bands_y, in_page = task % per_page;
+    page = task / per_page;
+    const uint32_t x0 = (in_page % strips_x) * S8_COLS;
+    y0 = (in_page / strips_x) * S8_ROWS;
+    xl = x0 + 4 * lane;  // the lane's first column = its first window
     // lanes right of the row read its zero padding (>= 64 zero bytes right of every row, focr_pages_alloc)
     const uint32_t off = xl + 4 <= pitch ? xl : pitch - 4;
     const uint8_t *pg = pages + (size_t)page * rows_alloc * pitch;
@@ -300,10 +309,10 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
     const bool store_lane = lane < S8_COLS / 4 && xl < Lpitch;
     const bool mark_lane = (lane & 3) == 0 && (xl >> 4) < mtx;
     char *outA = reinterpret_cast<char *>(A.out), *outB = reinterpret_cast<char *>(B.out);
-#pragma unroll 2
-    for (uint32_t k = 0; k < S8_ROWS; k++) {
+    const uint32_t k_end = y0 < Lrows ? (Lrows - y0 < S8_ROWS ? Lrows - y0 : S8_ROWS) : 0u;  // wave-uniform: the band's rows inside the planes
+
+    for (uint32_t k = 0; k < k_end; k++) {
         const uint32_t y = y0 + k;
-        if (y >= Lrows) break;  // wave-uniform
         // the rows that enter and leave when the window slides down: asked for now, used behind this row's arithmetic
         const uint32_t vi = load_row(y + n_h), vo = load_row(y);
         const uint32_t entry = ((page * Lrows + y) * Lpitch + xl) * 2u;  // byte offset of the lane's four values in a plane (a pass's planes span < 4 GiB)
@@ -372,7 +381,10 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
             }
             // M-tile marks: an M-tile is the 16 windows of four lanes (x0 is a multiple of 16)
             const uint64_t lm = __builtin_amdgcn_ballot_w64(any && store_lane);
-            if (mark_lane && ((lm >> lane) & 0xfu) && y <= n_rows) live[(page * n_rows + y - 1) * mtx + (xl >> 4)] = 1;
+            if (mark_lane && ((lm >> lane) & 0xfu) && y <= n_rows) {
+                if (APPEND) mymask |= 1u << k;
+                else live[(page * n_rows + y - 1) * mtx + (xl >> 4)] = 1;
+            }
         }
         {  // slide down one row
 #pragma unroll
@@ -381,6 +393,30 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
                 const int d = (int)bi - (int)bo;
                 c1[m] += (uint32_t)d;
                 c2[m] += (uint32_t)__mul24(d, (int)(bi + bo));
+            }
+        }
+    }
+    }  // task < n_tasks
+    if (APPEND) {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < S8_ROWS; k++) total += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((mymask >> k) & 1u));
+        if (lane == 0) wg_cnt[wv] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = wg_cnt[0] + wg_cnt[1] + wg_cnt[2] + wg_cnt[3];
+            wg_base = t ? atomicAdd(list_count, t) : 0u;
+        }
+        __syncthreads();
+        uint32_t run = wg_base;
+        for (uint32_t q = 0; q < wv; q++) run += wg_cnt[q];
+        if (total) {  // wave-uniform
+            for (uint32_t k = 0; k < S8_ROWS; k++) {
+                const bool mine = (mymask >> k) & 1u;
+                const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                // the scan kernel's entry: page << 32 | tile row (image row y - 1) << 12 | M-tile column (compact_live_tiles)
+                if (mine) list[run + rank] = ((uint64_t)page << 32) | ((uint64_t)(y0 + k - 1) << 12) | (xl >> 4);
+                run += (uint32_t)__builtin_popcountll(m);
             }
         }
     }
@@ -731,10 +767,17 @@ PlaneParams plane_params(const focr_ctx *c, size_t k, double thr_d) {
     return p;
 }
 
-// one statistics launch: class k (full box), optionally together with its kept box as class `pair` (< 0: none)
+// whether a size class's statistics take the register form (stats8_kernel): threshold planes, a kept width of 8 px
+static bool stats_register_form(const focr_ctx *c, const SizeClass &sc) {
+    static const bool no_s8 = getenv("FOCR_NO_STATS8") != nullptr;  // A/B: the LDS-tiled kernel for every class
+    return sc.keep_w == 8 && !no_s8 && c->dbg_stats_form == 0;
+}
+
+// one statistics launch: class k (full box), optionally together with its kept box as class `pair` (< 0: none);
+// append_list / append_count: the launch is the pass's only one and appends its live M-tiles to the work list itself (stats8_kernel, APPEND)
 template <int OUT>
 static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out, void *out_pair, uint32_t Lpitch, uint32_t Lrows, uint8_t *live,
-                        uint32_t mtx, uint32_t n_rows) {
+                        uint32_t mtx, uint32_t n_rows, uint64_t *append_list = nullptr, uint32_t *append_count = nullptr) {
     const SizeClass &sc = c->classes[k];
     // only what the scan kernels read: the windows of the pass's M-tiles (x < 16 * mtx) in the searched rows (y <= n_rows)
     dim3 grid(std::min<unsigned>(Lpitch / STX, (16 * mtx + STX - 1) / STX), std::min<unsigned>((Lrows + STY - 1) / STY, (n_rows + 1 + STY - 1) / STY),
@@ -742,8 +785,8 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
     StatsOut A{plane_params(c, k, thr_d), out}, B{};
     if (pair >= 0) B = StatsOut{plane_params(c, (size_t)pair, thr_d), out_pair};
     const bool drop = sc.keep_w != sc.n_w, small = sc.n_w * sc.n_h <= 256;
-    static const bool no_s8 = getenv("FOCR_NO_STATS8") != nullptr;  // A/B and the planes' equality test: the LDS-tiled kernel for every class
-    if (OUT == 1 && sc.keep_w == 8 && !no_s8 && c->dbg_stats_form == 0) {  // kept width 8: the register form (stats8_kernel)
+    if (append_list && !(OUT == 1 && stats_register_form(c, sc))) return fail(c, FOCR_ERR_INVALID, "scan_mfma: internal: direct append without the register form");
+    if (OUT == 1 && stats_register_form(c, sc)) {  // kept width 8: the register form (stats8_kernel)
         const uint32_t cols = std::min<uint32_t>(Lpitch, 16 * mtx), rows_n = std::min<uint32_t>(Lrows, n_rows + 1);
         const uint32_t strips_x = (cols + S8_COLS - 1) / S8_COLS, bands_y = (rows_n + S8_ROWS - 1) / S8_ROWS;
         const uint64_t n_tasks = (uint64_t)strips_x * bands_y * c->sub_np;
@@ -751,11 +794,18 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
         auto launch8 = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                                (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows, strips_x, bands_y,
-                               (uint32_t)n_tasks);
+                               (uint32_t)n_tasks, append_list, append_count);
         };
-        if (pair >= 0) small ? launch8(stats8_kernel<true, true, true>) : launch8(stats8_kernel<false, true, true>);
-        else if (drop) small ? launch8(stats8_kernel<true, true, false>) : launch8(stats8_kernel<false, true, false>);
-        else small ? launch8(stats8_kernel<true, false, false>) : launch8(stats8_kernel<false, false, false>);
+#define S8_FORMS(AP)                                                                                                                              \
+    if (pair >= 0) small ? launch8(stats8_kernel<true, true, true, AP>) : launch8(stats8_kernel<false, true, true, AP>);                          \
+    else if (drop) small ? launch8(stats8_kernel<true, true, false, AP>) : launch8(stats8_kernel<false, true, false, AP>);                        \
+    else small ? launch8(stats8_kernel<true, false, false, AP>) : launch8(stats8_kernel<false, false, false, AP>);
+        if (append_list) {
+            S8_FORMS(true)
+        } else {
+            S8_FORMS(false)
+        }
+#undef S8_FORMS
         FOCR_HIP(c, hipGetLastError());
         return FOCR_OK;
     }
@@ -931,6 +981,11 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             for (int pass = 0; pass < 2; pass++)
                 for (size_t v = 0; v < su.classes.size(); v++)
                     if ((c->classes[su.classes[v]].keep_w != c->classes[su.classes[v]].n_w) == (pass == 0)) order.push_back(v);
+            struct StatsLaunch {
+                size_t v, k, pv;
+                int pair;
+            };
+            std::vector<StatsLaunch> todo;  // the pass's statistics launches
             for (size_t v : order) {
                 if (done[v]) continue;
                 const size_t k = su.classes[v];
@@ -945,17 +1000,26 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
                         const SizeClass &o = c->classes[su.classes[u]];
                         if (u != v && !done[u] && o.n_w == sc.keep_w && o.n_h == sc.n_h && o.keep_w == o.n_w) pair = (int)su.classes[u], pv = u;
                     }
-                if (two[si]) {
-                    uint16_t *base = c->d_planes + plane_off[si];
-                    rc = launch_stats<1>(c, k, pair, thr_d, base + v * plane, pair >= 0 ? base + pv * plane : nullptr, Lpitch, Lrows, lv, su.mtx, su.n_rows);
-                } else {
-                    rc = launch_stats<0>(c, k, pair, thr_d, c->d_L + k * L_per_class, pair >= 0 ? c->d_L + (size_t)pair * L_per_class : nullptr, Lpitch, Lrows, lv,
-                                         su.mtx, su.n_rows);
-                }
-                if (rc) return rc;
+                todo.push_back(StatsLaunch{v, k, pv, pair});
                 done[v] = 1;
                 if (pair >= 0) done[pv] = 1;
             }
+            // ONE launch for the whole pass, in the register form: its marks are final and it appends the live M-tiles to the work
+            // list itself (stats8_kernel, APPEND) — no mark bytes, no compaction launch in front of the scan kernel
+            static const bool no_append = getenv("FOCR_NO_STATS_APPEND") != nullptr;  // A/B
+            const bool direct = two[si] && todo.size() == 1 && stats_register_form(c, c->classes[todo[0].k]) && !no_append;
+            for (const StatsLaunch &L : todo) {
+                if (two[si]) {
+                    uint16_t *base = c->d_planes + plane_off[si];
+                    rc = launch_stats<1>(c, L.k, L.pair, thr_d, base + L.v * plane, L.pair >= 0 ? base + L.pv * plane : nullptr, Lpitch, Lrows, lv, su.mtx, su.n_rows,
+                                         direct ? live_list + su.live_offset : nullptr, direct ? c->d_counter + 8 + si : nullptr);
+                } else {
+                    rc = launch_stats<0>(c, L.k, L.pair, thr_d, c->d_L + L.k * L_per_class, L.pair >= 0 ? c->d_L + (size_t)L.pair * L_per_class : nullptr, Lpitch, Lrows, lv,
+                                         su.mtx, su.n_rows);
+                }
+                if (rc) return rc;
+            }
+            if (direct) continue;
             const uint32_t nt = (uint32_t)((uint64_t)su.mtx * su.n_rows * c->sub_np);
             hipLaunchKernelGGL(compact_live_tiles, dim3((nt + 256 * CLT_PER_THREAD - 1) / (256 * CLT_PER_THREAD)), dim3(256), 0, c->stream, live + su.live_offset, nt, su.mtx,
                                su.n_rows, 1u, live_list + su.live_offset, c->d_counter + 8 + si);
