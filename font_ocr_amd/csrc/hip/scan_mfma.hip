@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
     const int a1 = (int)(lane + 1 < 64 ? lane + 1 : 63) * 4, a2 = (int)(lane + 2 < 64 ? lane + 2 : 63) * 4;  // ds_bpermute addresses
     const uint32_t n = n_w * n_h, n_k = (n_w - 1) * n_h;
     const bool store_lane = lane < S8_COLS / 4 && xl < Lpitch;
-    const bool mark_lane = (lane & 3) == 0 && (xl >> 4) < mtx;
+    const bool mark_lane = (lane & 3) == 0 && lane < S8_COLS / 4 && (xl >> 4) < mtx;  // a quad's first lane speaks for its M-tile; lanes 60..63 belong to the next strip
     char *outA = reinterpret_cast<char *>(A.out), *outB = reinterpret_cast<char *>(B.out);
     const uint32_t k_end = y0 < Lrows ? (Lrows - y0 < S8_ROWS ? Lrows - y0 : S8_ROWS) : 0u;  // wave-uniform: the band's rows inside the planes
 
@@ -386,6 +386,8 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
                 else live[(page * n_rows + y - 1) * mtx + (xl >> 4)] = 1;
             }
         }
+        // APPEND behind other statistics launches of the pass (their marks are in `live`): an M-tile they marked is live too
+        if (APPEND && live && mark_lane && y >= 1 && y <= n_rows && live[(page * n_rows + y - 1) * mtx + (xl >> 4)]) mymask |= 1u << k;
         {  // slide down one row
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -1007,12 +1009,17 @@ int launch_scan_mfma(focr_ctx *c, float threshold) {
             // ONE launch for the whole pass, in the register form: its marks are final and it appends the live M-tiles to the work
             // list itself (stats8_kernel, APPEND) — no mark bytes, no compaction launch in front of the scan kernel
             static const bool no_append = getenv("FOCR_NO_STATS_APPEND") != nullptr;  // A/B
-            const bool direct = two[si] && todo.size() == 1 && stats_register_form(c, c->classes[todo[0].k]) && !no_append;
+            // (several launches: one in the register form goes LAST and merges the marks the others left in `live`)
+            for (size_t i = 0; i + 1 < todo.size(); i++)
+                if (stats_register_form(c, c->classes[todo[i].k]) && !stats_register_form(c, c->classes[todo.back().k])) std::swap(todo[i], todo.back());
+            const bool direct = two[si] && !todo.empty() && stats_register_form(c, c->classes[todo.back().k]) && !no_append;
             for (const StatsLaunch &L : todo) {
                 if (two[si]) {
                     uint16_t *base = c->d_planes + plane_off[si];
-                    rc = launch_stats<1>(c, L.k, L.pair, thr_d, base + L.v * plane, L.pair >= 0 ? base + L.pv * plane : nullptr, Lpitch, Lrows, lv, su.mtx, su.n_rows,
-                                         direct ? live_list + su.live_offset : nullptr, direct ? c->d_counter + 8 + si : nullptr);
+                    const bool last = direct && &L == &todo.back();
+                    rc = launch_stats<1>(c, L.k, L.pair, thr_d, base + L.v * plane, L.pair >= 0 ? base + L.pv * plane : nullptr, Lpitch, Lrows,
+                                         last && todo.size() == 1 ? nullptr : lv, su.mtx, su.n_rows, last ? live_list + su.live_offset : nullptr,
+                                         last ? c->d_counter + 8 + si : nullptr);
                 } else {
                     rc = launch_stats<0>(c, L.k, L.pair, thr_d, c->d_L + L.k * L_per_class, L.pair >= 0 ? c->d_L + (size_t)L.pair * L_per_class : nullptr, Lpitch, Lrows, lv,
                                          su.mtx, su.n_rows);
