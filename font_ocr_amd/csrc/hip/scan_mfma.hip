@@ -310,8 +310,7 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
     const bool mark_lane = (lane & 3) == 0 && lane < S8_COLS / 4 && (xl >> 4) < mtx;  // a quad's first lane speaks for its M-tile; lanes 60..63 belong to the next strip
     char *outA = reinterpret_cast<char *>(A.out), *outB = reinterpret_cast<char *>(B.out);
     const uint32_t k_end = y0 < Lrows ? (Lrows - y0 < S8_ROWS ? Lrows - y0 : S8_ROWS) : 0u;  // wave-uniform: the band's rows inside the planes
-
-    for (uint32_t k = 0; k < k_end; k++) {
+    auto window_row = [&](uint32_t k) __attribute__((always_inline)) {
         const uint32_t y = y0 + k;
         // the rows that enter and leave when the window slides down: asked for now, used behind this row's arithmetic
         const uint32_t vi = load_row(y + n_h), vo = load_row(y);
@@ -397,7 +396,13 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
                 c2[m] += (uint32_t)__mul24(d, (int)(bi + bo));
             }
         }
+    };
+    uint32_t k = 0;
+    for (; k + 2 <= k_end; k += 2) {  // two window rows per trip: the second row's loads and lane exchanges overlap the first row's arithmetic
+        window_row(k);
+        window_row(k + 1);
     }
+    if (k < k_end) window_row(k);
     }  // task < n_tasks
     if (APPEND) {
         uint32_t total = 0;
