@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const uint8_t *__restrict__ 
     }
 }
 
-// The same statistics for a kept width of 8 columns (BASELINE configs[1] and [2]: 8-wide classes and 9-wide ones with their last column
-// dropped), VERTICAL sums first and no LDS: a lane owns four neighbouring columns (one dword of every page row), slides the
+// The same statistics for kept widths of 4, 8, 12 and 16 columns (8: BASELINE configs[1] and [2], 8-wide classes and 9-wide ones with
+// their last column dropped; the description below is for 8, template parameter KQ = 2), VERTICAL sums first and no LDS: a lane owns four neighbouring columns (one dword of every page row), slides the
 // n_h-row sums of its four columns down S8_ROWS window rows — C1 = sum of bytes, C2 = sum of squares, from the row that enters and
 // the row that leaves: d = in - out, C1 += d, C2 += d * (in + out) — and the horizontal 8-sums come out of the lanes' registers:
 // window x = 4L + i covers columns 4L + i .. 4L + i + 7 = the rest of lane L's dword, all of lane L + 1's, the first i columns
@@ -266,7 +266,9 @@ constexpr uint32_t S8_COLS = 240, S8_ROWS = 16;  // (8 / 24 / 32 rows per wave: 
 //   marked M-tile is final: instead of a mark byte for compact_live_tiles the wave remembers its marks (16 rows x 15 M-tiles: one
 //   bit per row in each quad's first lane) and appends them to the pass's work list itself, in row-major order, behind ONE atomic
 //   per workgroup — no mark bytes, no compaction launch between the statistics and the scan kernel.
-template <bool SMALLN, bool DROP, bool PAIR, bool APPEND>
+//   KQ = kept width / 4 (1 .. 4: kept widths 4, 8, 12, 16): window 4L + i then covers the rest of lane L's dword, lanes L + 1 .. L + KQ - 1
+//   whole and the first i columns of lane L + KQ, and the dropped column is column i of lane L + KQ.
+template <int KQ, bool SMALLN, bool DROP, bool PAIR, bool APPEND>
 __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
                                                      uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
                                                      uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
             }
         }
     }
-    const int a1 = (int)(lane + 1 < 64 ? lane + 1 : 63) * 4, a2 = (int)(lane + 2 < 64 ? lane + 2 : 63) * 4;  // ds_bpermute addresses
+    int an[KQ + 1];  // ds_bpermute addresses of lanes L + 1 .. L + KQ
+#pragma unroll
+    for (int q = 1; q <= KQ; q++) an[q] = (int)(lane + q < 64 ? lane + q : 63) * 4;
     const uint32_t n = n_w * n_h, n_k = (n_w - 1) * n_h;
     const bool store_lane = lane < S8_COLS / 4 && xl < Lpitch;
     const bool mark_lane = (lane & 3) == 0 && lane < S8_COLS / 4 && (xl >> 4) < mtx;  // a quad's first lane speaks for its M-tile; lanes 60..63 belong to the next strip
@@ -326,12 +330,17 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
             }
         } else {
             const uint32_t R1 = c1[0] + c1[1] + c1[2] + c1[3], R2 = c2[0] + c2[1] + c2[2] + c2[3];
-            uint32_t s_k = R1 + (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)R1), s2_k = R2 + (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)R2);
+            uint32_t s_k = R1, s2_k = R2;
+#pragma unroll
+            for (int q = 1; q < KQ; q++) {  // the whole lanes between
+                s_k += (uint32_t)__builtin_amdgcn_ds_bpermute(an[q], (int)R1);
+                s2_k += (uint32_t)__builtin_amdgcn_ds_bpermute(an[q], (int)R2);
+            }
             uint32_t e1[4], e2[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                e1[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)c1[m]);
-                e2[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)c2[m]);
+                e1[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(an[KQ], (int)c1[m]);
+                e2[m] = (uint32_t)__builtin_amdgcn_ds_bpermute(an[KQ], (int)c2[m]);
             }
             int16_t va[4], vb[4];
             bool any = false;
@@ -777,7 +786,8 @@ PlaneParams plane_params(const focr_ctx *c, size_t k, double thr_d) {
 // whether a size class's statistics take the register form (stats8_kernel): threshold planes, a kept width of 8 px
 static bool stats_register_form(const focr_ctx *c, const SizeClass &sc) {
     static const bool no_s8 = getenv("FOCR_NO_STATS8") != nullptr;  // A/B: the LDS-tiled kernel for every class
-    return sc.keep_w == 8 && !no_s8 && c->dbg_stats_form == 0;
+    // kept widths 4, 8, 12, 16 (a dropped column only exists for 9 -> 8 and 13 -> 12: layout_supers)
+    return sc.keep_w % 4 == 0 && sc.keep_w >= 4 && sc.keep_w <= 16 && !no_s8 && c->dbg_stats_form == 0;
 }
 
 // one statistics launch: class k (full box), optionally together with its kept box as class `pair` (< 0: none);
@@ -803,16 +813,26 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
                                (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows, strips_x, bands_y,
                                (uint32_t)n_tasks, append_list, append_count);
         };
+#define S8_DROPS(KQ, AP)                                                                                                                         \
+    if (pair >= 0) small ? launch8(stats8_kernel<KQ, true, true, true, AP>) : launch8(stats8_kernel<KQ, false, true, true, AP>);                  \
+    else if (drop) small ? launch8(stats8_kernel<KQ, true, true, false, AP>) : launch8(stats8_kernel<KQ, false, true, false, AP>);                \
+    else small ? launch8(stats8_kernel<KQ, true, false, false, AP>) : launch8(stats8_kernel<KQ, false, false, false, AP>);
+#define S8_PLAIN(KQ, AP) small ? launch8(stats8_kernel<KQ, true, false, false, AP>) : launch8(stats8_kernel<KQ, false, false, false, AP>);
 #define S8_FORMS(AP)                                                                                                                              \
-    if (pair >= 0) small ? launch8(stats8_kernel<true, true, true, AP>) : launch8(stats8_kernel<false, true, true, AP>);                          \
-    else if (drop) small ? launch8(stats8_kernel<true, true, false, AP>) : launch8(stats8_kernel<false, true, false, AP>);                        \
-    else small ? launch8(stats8_kernel<true, false, false, AP>) : launch8(stats8_kernel<false, false, false, AP>);
+    switch (sc.keep_w) {                                                                                                                          \
+        case 4: S8_PLAIN(1, AP) break;                                                                                                            \
+        case 8: S8_DROPS(2, AP) break;                                                                                                            \
+        case 12: S8_DROPS(3, AP) break;                                                                                                           \
+        default: S8_PLAIN(4, AP) break;                                                                                                           \
+    }
         if (append_list) {
             S8_FORMS(true)
         } else {
             S8_FORMS(false)
         }
 #undef S8_FORMS
+#undef S8_PLAIN
+#undef S8_DROPS
         FOCR_HIP(c, hipGetLastError());
         return FOCR_OK;
     }

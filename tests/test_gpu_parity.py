@@ -108,12 +108,13 @@ def test_threshold_plane_values_device_equals_host(scanner):
         assert host.min() >= -32767  # -32768 is the "never" value: a threshold never maps to it
 
 
-@pytest.mark.parametrize("shapes", [[(9, 15), (8, 15)], [(9, 15)], [(8, 15)], [(8, 32), (9, 32)], [(8, 4), (9, 7)]],
-                         ids=["pair", "drop", "plain", "tall32", "short"])
+@pytest.mark.parametrize("shapes", [[(9, 15), (8, 15)], [(9, 15)], [(8, 15)], [(8, 32), (9, 32)], [(8, 4), (9, 7)],
+                                    [(13, 16), (12, 16)], [(13, 14)], [(16, 16)], [(4, 9), (4, 12)], [(12, 15), (8, 15)]],
+                         ids=["pair", "drop", "plain", "tall32", "short", "pair12", "drop12", "w16", "w4", "w12w8"])
 @pytest.mark.parametrize("geom", [(3, 301, 111), (2, 608, 720), (5, 64, 40), (1, 1021, 67)], ids=["301x111", "608x720", "64x40", "1021x67"])
 def test_statistics_register_form_writes_the_same_planes(shapes, geom):
-    """Classes whose kept width is 8 px take the register form of the window statistics (stats8_kernel: vertical sums first, a lane
-    per four columns, no LDS); every other class the LDS-tiled kernel.  Both must leave the same int16 threshold planes wherever the
+    """Classes whose kept width is 4, 8, 12 or 16 px take the register form of the window statistics (stats8_kernel: vertical sums
+    first, a lane per four columns, no LDS); every other class the LDS-tiled kernel.  Both must leave the same int16 threshold planes wherever the
     scan kernel reads them (x < 16 * mtx, y <= n_rows) and the same live M-tiles — hence the same candidates, hits and lines —
     for every geometry: widths that are no multiple of 4, strips that end inside / beyond the row's padding, pages lower than a band."""
     np_, r_w, r_h = geom
