@@ -268,21 +268,24 @@ constexpr uint32_t S8_COLS = 240, S8_ROWS = 16;  // (8 / 24 / 32 rows per wave: 
 //   per workgroup — no mark bytes, no compaction launch between the statistics and the scan kernel.
 //   KQ = kept width / 4 (1 .. 4: kept widths 4, 8, 12, 16): window 4L + i then covers the rest of lane L's dword, lanes L + 1 .. L + KQ - 1
 //   whole and the first i columns of lane L + KQ, and the dropped column is column i of lane L + KQ.
+//   A workgroup is GS neighbouring strips x GB bands one below the other (up to 16 waves), and it appends in the order (band, window
+//   row, strip): the work list then holds a page in blocks of whole page rows, GB x 16 rows tall, as compact_live_tiles' did (4 096
+//   M-tiles per block) — the scan kernel's neighbouring items share the page rows their windows overlap in and the planes' cache lines.
 template <int KQ, bool SMALLN, bool DROP, bool PAIR, bool APPEND>
-__global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
-                                                     uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
-                                                     uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
-                                                     uint32_t n_tasks, uint64_t *__restrict__ list, uint32_t *__restrict__ list_count) {
-    __shared__ uint32_t wg_cnt[4];
+__global__ __launch_bounds__(1024) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
+                                                      uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
+                                                      uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
+                                                      uint32_t GS, uint32_t GB, uint32_t sgroups, uint32_t bgroups, uint64_t *__restrict__ list,
+                                                      uint32_t *__restrict__ list_count) {
+    __shared__ uint32_t wg_cnt[16][S8_ROWS], wg_off[16][S8_ROWS];  // [wave][window row]: live M-tiles, and where they go inside the workgroup's block
+    __shared__ uint32_t wg_wsum[4];
     __shared__ uint32_t wg_base;
     const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t task = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    uint32_t mymask = 0, page = 0, y0 = 0, xl = 0;  // APPEND: bit k = the M-tile of this quad is live in window row y0 + k
-    if (task < n_tasks) {  // wave-uniform (without APPEND there is no barrier below and the wave could simply leave)
-    const uint32_t per_page = strips_x * bands_y, in_page = task % per_page;
-    page = task / per_page;
-    const uint32_t x0 = (in_page % strips_x) * S8_COLS;
-    y0 = (in_page / strips_x) * S8_ROWS;
+    const uint32_t per_page = sgroups * bgroups, in_page = blockIdx.x % per_page;
+    const uint32_t band = (in_page / sgroups) * GB + wv / GS, strip = (in_page % sgroups) * GS + wv % GS;
+    uint32_t mymask = 0, page = blockIdx.x / per_page, y0 = band * S8_ROWS, xl = 0;  // APPEND: bit k = the M-tile of this quad is live in window row y0 + k
+    if (strip < strips_x && band < bands_y) {  // wave-uniform (the workgroup's last strips / bands may lie outside the page)
+    const uint32_t x0 = strip * S8_COLS;
     xl = x0 + 4 * lane;  // the lane's first column = its first window
     // lanes right of the row read its zero padding (>= 64 zero bytes right of every row, focr_pages_alloc)
     const uint32_t off = xl + 4 <= pitch ? xl : pitch - 4;
@@ -412,28 +415,57 @@ __global__ __launch_bounds__(256) void stats8_kernel(const uint8_t *__restrict__
         window_row(k + 1);
     }
     if (k < k_end) window_row(k);
-    }  // task < n_tasks
+    }  // a strip and a band of the page
     if (APPEND) {
-        uint32_t total = 0;
-        for (uint32_t k = 0; k < S8_ROWS; k++) total += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((mymask >> k) & 1u));
-        if (lane == 0) wg_cnt[wv] = total;
+        uint32_t mycnt = 0;  // lane k < 16: this wave's live M-tiles in window row k
+        for (uint32_t k = 0; k < S8_ROWS; k++) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((mymask >> k) & 1u));
+            if (lane == k) mycnt = cnt;
+        }
+        if (lane < S8_ROWS) wg_cnt[wv][lane] = mycnt;
+        if (threadIdx.x < 4) wg_wsum[threadIdx.x] = 0;  // (a workgroup may have fewer than four waves)
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t t = wg_cnt[0] + wg_cnt[1] + wg_cnt[2] + wg_cnt[3];
-            wg_base = t ? atomicAdd(list_count, t) : 0u;
+        // exclusive prefix of the counts in the block's order (band, window row, strip): cell o = (band * 16 + row) * GS + strip, one
+        // thread of the first four waves per cell (at most 16 waves x 16 rows = 256 cells)
+        const uint32_t o = threadIdx.x, n_cells = GS * GB * S8_ROWS;
+        uint32_t cw = 0, ck = 0, v = 0;
+        if (o < 256 && o < n_cells) {
+            const uint32_t s_ = o % GS, bk = o / GS;
+            ck = bk % S8_ROWS;
+            cw = (bk / S8_ROWS) * GS + s_;
+            v = wg_cnt[cw][ck];
+        }
+        if (o < 256) {  // wave-uniform: waves 0 .. 3
+            uint32_t incl = v;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wg_wsum[wv] = incl;
+            v = incl - v;  // exclusive inside the wave
         }
         __syncthreads();
-        uint32_t run = wg_base;
-        for (uint32_t q = 0; q < wv; q++) run += wg_cnt[q];
-        if (total) {  // wave-uniform
-            for (uint32_t k = 0; k < S8_ROWS; k++) {
-                const bool mine = (mymask >> k) & 1u;
-                const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                // the scan kernel's entry: page << 32 | tile row (image row y - 1) << 12 | M-tile column (compact_live_tiles)
-                if (mine) list[run + rank] = ((uint64_t)page << 32) | ((uint64_t)(y0 + k - 1) << 12) | (xl >> 4);
-                run += (uint32_t)__builtin_popcountll(m);
+        if (o < 256) {
+            uint32_t before = 0;
+            for (uint32_t q = 0; q < wv; q++) before += wg_wsum[q];
+            if (o < n_cells) wg_off[cw][ck] = before + v;
+            if (o == 0) {
+                const uint32_t t = wg_wsum[0] + wg_wsum[1] + wg_wsum[2] + wg_wsum[3];
+                wg_base = t ? atomicAdd(list_count, t) : 0u;
             }
+        }
+        __syncthreads();
+        const uint32_t base = wg_base;
+        const uint32_t myoff = lane < S8_ROWS ? wg_off[wv][lane] : 0u;
+        for (uint32_t k = 0; k < S8_ROWS; k++) {
+            const bool mine = (mymask >> k) & 1u;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+            if (m == 0) continue;  // wave-uniform
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t row_at = base + (uint32_t)__builtin_amdgcn_readlane((int)myoff, (int)k);
+            // the scan kernel's entry: page << 32 | tile row (image row y - 1) << 12 | M-tile column (compact_live_tiles)
+            if (mine) list[row_at + rank] = ((uint64_t)page << 32) | ((uint64_t)(y0 + k - 1) << 12) | (xl >> 4);
         }
     }
 }
@@ -806,12 +838,16 @@ static int launch_stats(focr_ctx *c, size_t k, int pair, double thr_d, void *out
     if (OUT == 1 && stats_register_form(c, sc)) {  // kept width 8: the register form (stats8_kernel)
         const uint32_t cols = std::min<uint32_t>(Lpitch, 16 * mtx), rows_n = std::min<uint32_t>(Lrows, n_rows + 1);
         const uint32_t strips_x = (cols + S8_COLS - 1) / S8_COLS, bands_y = (rows_n + S8_ROWS - 1) / S8_ROWS;
-        const uint64_t n_tasks = (uint64_t)strips_x * bands_y * c->sub_np;
-        if (n_tasks >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
+        // a workgroup: GS neighbouring strips x GB bands, at most 16 waves (stats8_kernel)
+        static const uint32_t gb_max = getenv("FOCR_S8_GB") ? (uint32_t)atoi(getenv("FOCR_S8_GB")) : 2u;  // 1 .. 5 measured: 34.15 / 34.60 / 33.89 / 34.23 / 33.70 Gpx/s (tools/r5_gb.sh)
+        const uint32_t GS = std::min<uint32_t>(strips_x, 16), GB = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(16 / GS, gb_max), bands_y));
+        const uint32_t sgroups = (strips_x + GS - 1) / GS, bgroups = (bands_y + GB - 1) / GB;
+        const uint64_t n_wgs = (uint64_t)sgroups * bgroups * c->sub_np;
+        if (n_wgs >= 0x7fffffffull) return fail(c, FOCR_ERR_INVALID, "scan_mfma: batch too large for 32-bit tile ids; scan fewer pages per call");
         auto launch8 = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_wgs), dim3(GS * GB * 64), 0, c->stream, c->d_pages + c->sub_p0 * c->rows_alloc * c->pitch, (uint32_t)c->pitch,
                                (uint32_t)c->rows_alloc, (uint32_t)c->r_w, (uint32_t)c->r_h, sc.n_w, sc.n_h, A, B, Lpitch, Lrows, live, mtx, n_rows, strips_x, bands_y,
-                               (uint32_t)n_tasks, append_list, append_count);
+                               GS, GB, sgroups, bgroups, append_list, append_count);
         };
 #define S8_DROPS(KQ, AP)                                                                                                                         \
     if (pair >= 0) small ? launch8(stats8_kernel<KQ, true, true, true, AP>) : launch8(stats8_kernel<KQ, false, true, true, AP>);                  \
