@@ -272,7 +272,7 @@ constexpr uint32_t S8_COLS = 240, S8_ROWS = 16;  // (8 / 24 / 32 rows per wave: 
 //   row, strip): the work list then holds a page in blocks of whole page rows, GB x 16 rows tall, as compact_live_tiles' did (4 096
 //   M-tiles per block) — the scan kernel's neighbouring items share the page rows their windows overlap in and the planes' cache lines.
 template <int KQ, bool SMALLN, bool DROP, bool PAIR, bool APPEND>
-__global__ __launch_bounds__(1024) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void stats8_kernel(const uint8_t *__restrict__ pages, uint32_t pitch, uint32_t rows_alloc, uint32_t r_w, uint32_t r_h,
                                                       uint32_t n_w, uint32_t n_h, const StatsOut A, const StatsOut B, uint32_t Lpitch, uint32_t Lrows,
                                                       uint8_t *__restrict__ live, uint32_t mtx, uint32_t n_rows, uint32_t strips_x, uint32_t bands_y,
                                                       uint32_t GS, uint32_t GB, uint32_t sgroups, uint32_t bgroups, uint64_t *__restrict__ list,
